@@ -1,0 +1,218 @@
+"""ctypes binding of the C ABI in include/gsraster.h (libgsraster_hip.so).
+
+This is the reference-side binding a Python host would use; the C++/LibTorch operator surface
+(csrc/torch_binding.cpp) goes through the same ABI.  Device memory, streams and allocation are
+PyTorch-ROCm plumbing; all compute is in the HIP library.  There is NO CPU fallback: if the
+library is missing or a call fails, this module raises.
+"""
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgsraster_hip.so")
+
+ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
+
+
+class GeometryView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in
+                ("depths", "radii", "splats", "cov3D", "tiles_touched", "point_offsets", "clamped")]
+
+
+class BinningView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("keys_unsorted", "values_unsorted", "keys", "point_list")]
+
+
+class ImageView(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in ("ranges", "final_T", "n_contrib")]
+
+
+_lib = None
+
+EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_bytes", "gsr_image_bytes",
+           "gsr_binning_bytes", "gsr_geometry_view_of", "gsr_binning_view_of", "gsr_image_view_of",
+           "gsr_higher_msb", "gsr_last_error", "gsr_abi_version")
+
+
+def lib():
+    """Loads libgsraster_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "libgsraster_hip.so not built: run `python gs-livm_amd/build.py` (needs hipcc). "
+            "gs_livm_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, ci, cf, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+    L.gsr_forward.restype = ci
+    L.gsr_forward.argtypes = [ALLOC_FN, vp, ALLOC_FN, vp, ALLOC_FN, vp, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, vp, cf,
+                              vp, vp, vp, vp, vp, cf, cf, ci, vp, vp, vp, vp, ci, vp]
+    L.gsr_backward.restype = ci
+    L.gsr_backward.argtypes = [ci, ci, ci, ci, vp, ci, ci, vp, vp, vp, vp, cf, vp, vp, vp, vp, vp, cf, cf, vp, vp, vp,
+                               vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, ci, vp]
+    L.gsr_mark_visible.restype = ci
+    L.gsr_mark_visible.argtypes = [ci, vp, vp, vp, vp, vp]
+    for n in ("gsr_geometry_bytes", "gsr_binning_bytes"):
+        getattr(L, n).restype = sz
+        getattr(L, n).argtypes = [ci]
+    L.gsr_image_bytes.restype = sz
+    L.gsr_image_bytes.argtypes = [ci, ci]
+    L.gsr_geometry_view_of.argtypes = [vp, ci, C.POINTER(GeometryView)]
+    L.gsr_binning_view_of.argtypes = [vp, ci, C.POINTER(BinningView)]
+    L.gsr_image_view_of.argtypes = [vp, ci, ci, C.POINTER(ImageView)]
+    L.gsr_higher_msb.restype = C.c_uint32
+    L.gsr_higher_msb.argtypes = [C.c_uint32]
+    L.gsr_last_error.restype = C.c_char_p
+    L.gsr_abi_version.restype = ci
+    _lib = L
+    return L
+
+
+class GsrError(RuntimeError):
+    pass
+
+
+def _check(code):
+    if code < 0:
+        raise GsrError("libgsraster_hip error %d: %s" % (code, lib().gsr_last_error().decode()))
+    return code
+
+
+def _ptr(t):
+    """Device pointer of a tensor; size-0 / None -> NULL (the reference's convention,
+    src/gs/rasterizer.cu:178-193)."""
+    if t is None or t.numel() == 0:
+        return None
+    assert t.is_cuda and t.is_contiguous(), "expects contiguous device tensors"
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Blob:
+    """Allocator callback target: replaces resizeFunctional (src/gs/rasterize_points.cu:36-44)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.tensor = torch.empty(0, dtype=torch.uint8, device=device)
+        self.fn = ALLOC_FN(self._alloc)
+
+    def _alloc(self, _ctx, nbytes):
+        try:
+            self.tensor = torch.empty(int(nbytes), dtype=torch.uint8, device=self.device)
+            return self.tensor.data_ptr()
+        except Exception:  # pragma: no cover - surfaces as GSR_ERR_ALLOC
+            return None
+
+
+def rasterize_forward(background, means3D, colors, opacity, scales, rotations, scale_modifier, cov3D_precomp,
+                      viewmatrix, projmatrix, tan_fovx, tan_fovy, image_height, image_width, sh, degree, campos,
+                      prefiltered=False, debug=False, radii_out=True):
+    """Mirror of RasterizeGaussiansCUDA (src/gs/rasterize_points.cu:46-130) over the C ABI.
+    Returns (num_rendered, out_color, out_depth, out_acc, radii, geomBuffer, binningBuffer, imgBuffer)."""
+    if means3D.dim() != 2 or means3D.size(1) != 3:
+        raise ValueError("means3D must have dimensions (num_points, 3)")
+    dev = means3D.device
+    P, H, W = int(means3D.size(0)), int(image_height), int(image_width)
+    f32 = dict(dtype=torch.float32, device=dev)
+    out_color = torch.empty((3, H, W), **f32)
+    out_depth = torch.empty((1, H, W), **f32)
+    out_acc = torch.empty((1, H, W), **f32)
+    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    gb, bb, ib = _Blob(dev), _Blob(dev), _Blob(dev)
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    L = lib()
+    R = _check(L.gsr_forward(gb.fn, None, bb.fn, None, ib.fn, None, P, int(degree), M, _ptr(background), W, H,
+                             _ptr(means3D), _ptr(sh), _ptr(colors), _ptr(opacity), _ptr(scales),
+                             float(scale_modifier), _ptr(rotations), _ptr(cov3D_precomp), _ptr(viewmatrix),
+                             _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
+                             _ptr(out_color), _ptr(out_depth), _ptr(out_acc), _ptr(radii) if radii_out else None,
+                             int(bool(debug)), _stream()))
+    return R, out_color, out_depth, out_acc, radii, gb.tensor, bb.tensor, ib.tensor
+
+
+def rasterize_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                       viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_acc, sh, degree, campos,
+                       geomBuffer, R, binningBuffer, imageBuffer, debug=False, return_conic=False):
+    """Mirror of RasterizeGaussiansBackwardCUDA (src/gs/rasterize_points.cu:132-224).
+    Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    [+ dL_dconic when return_conic]."""
+    dev = means3D.device
+    P = int(means3D.size(0))
+    H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
+    M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
+    f32 = dict(dtype=torch.float32, device=dev)
+    # the library overwrites every element, so torch.empty replaces the reference's nine torch::zeros
+    # (rasterize_points.cu:173-181); P == 0 needs the zeros (nothing runs).
+    mk = torch.zeros if P == 0 else torch.empty
+    dL_dmeans3D = mk((P, 3), **f32)
+    dL_dmeans2D = mk((P, 3), **f32)
+    dL_dcolors = mk((P, 3), **f32)
+    dL_dconic = mk((P, 2, 2), **f32)
+    dL_dopacity = mk((P, 1), **f32)
+    dL_dcov3D = mk((P, 6), **f32)
+    dL_dsh = mk((P, M, 3), **f32)
+    dL_dscales = mk((P, 3), **f32)
+    dL_drotations = mk((P, 4), **f32)
+    if P != 0:
+        dpix = dL_dout_color.contiguous()
+        dacc = dL_dout_acc.contiguous()
+        _check(lib().gsr_backward(P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh),
+                                  _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations),
+                                  _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
+                                  float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer),
+                                  _ptr(binningBuffer), _ptr(imageBuffer), _ptr(dpix), _ptr(dacc), _ptr(dL_dmeans2D),
+                                  _ptr(dL_dconic), _ptr(dL_dopacity), _ptr(dL_dcolors), _ptr(dL_dmeans3D),
+                                  _ptr(dL_dcov3D), _ptr(dL_dsh), _ptr(dL_dscales), _ptr(dL_drotations),
+                                  int(bool(debug)), _stream()))
+    out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
+    return out + (dL_dconic,) if return_conic else out
+
+
+def mark_visible(means3D, viewmatrix, projmatrix):
+    """Mirror of markVisible (src/gs/rasterize_points.cu:226-241)."""
+    P = int(means3D.size(0))
+    present = torch.zeros((P,), dtype=torch.bool, device=means3D.device)
+    if P:
+        _check(lib().gsr_mark_visible(P, _ptr(means3D), _ptr(viewmatrix), _ptr(projmatrix),
+                                      C.c_void_p(present.data_ptr()), _stream()))
+    return present
+
+
+def _sub(blob, ptr, count, dtype):
+    if not ptr or count == 0:
+        return None
+    off = int(ptr) - blob.data_ptr()
+    nbytes = count * torch.empty((), dtype=dtype).element_size()
+    return blob[off:off + nbytes].view(dtype)
+
+
+def state_views(geomBuffer, binningBuffer, imageBuffer, P, R, W, H):
+    """Typed tensor views into the three opaque blobs (tests / tooling)."""
+    L = lib()
+    gv, bv, iv = GeometryView(), BinningView(), ImageView()
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    out = {}
+    if P:
+        _check(L.gsr_geometry_view_of(_ptr(geomBuffer), P, C.byref(gv)))
+        out.update(depths=_sub(geomBuffer, gv.depths, P, torch.float32),
+                   radii=_sub(geomBuffer, gv.radii, P, torch.int32),
+                   splats=_sub(geomBuffer, gv.splats, P * 12, torch.float32).view(P, 12),
+                   cov3D=_sub(geomBuffer, gv.cov3D, P * 6, torch.float32).view(P, 6),
+                   tiles_touched=_sub(geomBuffer, gv.tiles_touched, P, torch.int32),
+                   point_offsets=_sub(geomBuffer, gv.point_offsets, P, torch.int32),
+                   clamped=_sub(geomBuffer, gv.clamped, P, torch.uint8))
+        _check(L.gsr_image_view_of(_ptr(imageBuffer), W, H, C.byref(iv)))
+        out.update(ranges=_sub(imageBuffer, iv.ranges, T * 2, torch.int32).view(T, 2),
+                   final_T=_sub(imageBuffer, iv.final_T, W * H, torch.float32).view(H, W),
+                   n_contrib=_sub(imageBuffer, iv.n_contrib, W * H, torch.int32).view(H, W))
+        if R:
+            _check(L.gsr_binning_view_of(_ptr(binningBuffer), R, C.byref(bv)))
+            out.update(keys=_sub(binningBuffer, bv.keys, R, torch.int64),
+                       point_list=_sub(binningBuffer, bv.point_list, R, torch.int32))
+    return out

@@ -1,0 +1,227 @@
+// api.hip -- the C ABI of libgsraster_hip.so (include/gsraster.h): argument checks, blob carving and
+// stage sequencing.  Restates the ORCHESTRATION of CudaRasterizer::Rasterizer::forward / backward
+// (reference rasterizer_impl.cu:181-342, :346-457); all device work is in the sibling .hip files.
+#include "../../include/gsraster.h"
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+
+#include "gsr_internal.hpp"
+
+using namespace gsr;
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                             \
+  do {                                                                                            \
+    hipError_t e_ = (expr);                                                                       \
+    if (e_ != hipSuccess) return fail(GSR_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_));       \
+  } while (0)
+
+// debug != 0: synchronise after the stage so a faulting kernel is reported where it ran
+// (the reference's CHECK_CUDA, auxiliary.h:146-154).
+#define STAGE(expr)                                                                               \
+  do {                                                                                            \
+    HIP_TRY(expr);                                                                                \
+    if (debug) HIP_TRY(hipStreamSynchronize(stream));                                             \
+  } while (0)
+
+extern "C" {
+
+const char* gsr_last_error(void) { return g_err; }
+int gsr_abi_version(void) { return GSR_ABI_VERSION; }
+
+uint32_t gsr_higher_msb(uint32_t n) {
+  // smallest b such that n < 2^b, found by bisection like the reference (rasterizer_impl.cu:35-48)
+  uint32_t msb = 16, step = 16;
+  while (step > 1) {
+    step >>= 1;
+    msb = (n >> msb) ? msb + step : msb - step;
+  }
+  if (n >> msb) msb++;
+  return msb;
+}
+
+size_t gsr_geometry_bytes(int P) {
+  size_t b = 0;
+  GeomState::carve(nullptr, (size_t)(P > 0 ? P : 0), &b);
+  return b;
+}
+size_t gsr_image_bytes(int width, int height) {
+  size_t b = 0;
+  ImageState::carve(nullptr, width, height, &b);
+  return b;
+}
+size_t gsr_binning_bytes(int R) {
+  size_t b = 0;
+  BinningState::carve(nullptr, (size_t)(R > 0 ? R : 0), &b);
+  return b;
+}
+
+static FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float tan_fovy, float scale_mod) {
+  FrameParams fp;
+  fp.P = P; fp.D = D; fp.M = M; fp.W = W; fp.H = H;
+  fp.gx = (W + TILE - 1) / TILE;
+  fp.gy = (H + TILE - 1) / TILE;
+  fp.tan_fovx = tan_fovx;
+  fp.tan_fovy = tan_fovy;
+  fp.focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:210-211
+  fp.focal_x = W / (2.0f * tan_fovx);
+  fp.scale_modifier = scale_mod;
+  return fp;
+}
+
+int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
+                gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
+                int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_acc,
+                int* radii, int debug, void* stream_) {
+  (void)prefiltered;  // no effect in the reference forward either
+  hipStream_t stream = (hipStream_t)stream_;
+  g_err[0] = 0;
+  if (P < 0 || width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad P/width/height");
+  if (!out_color || !out_depth || !out_acc) return fail(GSR_ERR_INVALID_ARGUMENT, "null output image");
+  const size_t N = (size_t)width * height;
+  if (P == 0) {  // the Torch glue never calls the rasterizer for P == 0 and returns zero images
+                 // (rasterize_points.cu:78-93); same result here.
+    HIP_TRY(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), stream));
+    HIP_TRY(hipMemsetAsync(out_depth, 0, N * sizeof(float), stream));
+    HIP_TRY(hipMemsetAsync(out_acc, 0, N * sizeof(float), stream));
+    return 0;
+  }
+  if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(GSR_ERR_INVALID_ARGUMENT, "null allocator");
+  if (!means3D || !opacities || !background || !viewmatrix || !projmatrix || !cam_pos)
+    return fail(GSR_ERR_INVALID_ARGUMENT, "null required input");
+  if (!colors_precomp && !shs)  // reference: NUM_CHANNELS/colour check, rasterizer_impl.cu:229-231
+    return fail(GSR_ERR_INVALID_ARGUMENT, "provide SHs or precomputed colours");
+  if (!cov3D_precomp && (!scales || !rotations))
+    return fail(GSR_ERR_INVALID_ARGUMENT, "provide scales+rotations or a precomputed 3D covariance");
+  if (!colors_precomp && (D < 0 || D > 3 || M < (D + 1) * (D + 1) || M > 16))
+    return fail(GSR_ERR_UNSUPPORTED, "SH degree %d with %d coefficients is not supported (D<=3, (D+1)^2<=M<=16)", D, M);
+  if (width > 1023 * TILE || height > 1023 * TILE) return fail(GSR_ERR_UNSUPPORTED, "image larger than 16368 px");
+  if (!(tan_fovx > 0.f) || !(tan_fovy > 0.f)) return fail(GSR_ERR_INVALID_ARGUMENT, "tan_fov must be > 0");
+
+  const FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
+  char* gblob = geometry_alloc(geometry_ctx, gsr_geometry_bytes(P));
+  if (!gblob) return fail(GSR_ERR_ALLOC, "geometry allocator returned NULL");
+  char* iblob = image_alloc(image_ctx, gsr_image_bytes(width, height));
+  if (!iblob) return fail(GSR_ERR_ALLOC, "image allocator returned NULL");
+  GeomState g = GeomState::carve(gblob, (size_t)P);
+  ImageState im = ImageState::carve(iblob, width, height);
+
+  STAGE(launch_preprocess(fp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
+                          projmatrix, cam_pos, g, radii, stream));
+  STAGE(launch_scan_block_sums(g, P, stream));
+  // R must be known on the host to size the binning blob: one blocking 4-byte read-back, exactly
+  // where the reference has its cudaMemcpy (rasterizer_impl.cu:277).
+  uint32_t R_host = 0;
+  HIP_TRY(hipMemcpyAsync(&R_host, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  HIP_TRY(hipStreamSynchronize(stream));
+  if (R_host > 0x7fffffffu) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31 splat instances");
+  const int R = (int)R_host;
+
+  char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(R));
+  if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
+  BinningState b = BinningState::carve(bblob, (size_t)R);
+
+  const int tiles = fp.gx * fp.gy;
+  const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:295
+  const bool start_in_A = (sort_passes(end_bit) % 2) == 0;
+  STAGE(launch_duplicate(fp, g, start_in_A ? b.keysA : b.keysB, start_in_A ? b.point_list : b.valsB, stream));
+  STAGE(launch_sort_pairs(b, R, end_bit, start_in_A, stream));
+  STAGE(launch_tile_ranges(b.keysA, R, im.ranges, tiles, stream));
+  STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
+  return R;
+}
+
+int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                 char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                 const float* dL_dacc, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                 void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  g_err[0] = 0;
+  if (P < 0 || R < 0 || width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad P/R/width/height");
+  if (P == 0) return GSR_OK;
+  if (!geom_buffer || !binning_buffer || !image_buffer) return fail(GSR_ERR_INVALID_ARGUMENT, "null state blob");
+  if (!means3D || !background || !viewmatrix || !projmatrix || !campos || !dL_dpix || !dL_dacc)
+    return fail(GSR_ERR_INVALID_ARGUMENT, "null required input");
+  if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
+      (M > 0 && !dL_dsh))
+    return fail(GSR_ERR_INVALID_ARGUMENT, "null gradient output");
+  const FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
+  GeomState g = GeomState::carve(geom_buffer, (size_t)P);
+  BinningState b = BinningState::carve(binning_buffer, (size_t)R);
+  ImageState im = ImageState::carve(image_buffer, width, height);
+  if (!radii) radii = g.radii;  // rasterizer_impl.cu:386-388
+  const float* cov3D_used = cov3D_precomp ? cov3D_precomp : g.cov3D;  // rasterizer_impl.cu:427
+
+  if (R > 0) {
+    STAGE(hipMemsetAsync(b.inst_flag, 0, (size_t)R, stream));
+    STAGE(launch_blend_backward(fp, g, b, im, background, dL_dpix, dL_dacc, stream));
+  }
+  STAGE(launch_gaussian_backward(fp, g, b, radii, means3D, scales, rotations, colors_precomp ? nullptr : shs,
+                                 cov3D_used, viewmatrix, projmatrix, campos, colors_precomp != nullptr, dL_dmean2D,
+                                 dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                                 stream));
+  return GSR_OK;
+}
+
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     unsigned char* present, void* stream_) {
+  (void)projmatrix;  // unused by the reference as well (auxiliary.h:130-135: the x/y test is commented out)
+  g_err[0] = 0;
+  if (P < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad P");
+  if (P == 0) return GSR_OK;
+  if (!means3D || !viewmatrix || !present) return fail(GSR_ERR_INVALID_ARGUMENT, "null pointer");
+  HIP_TRY(launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_));
+  return GSR_OK;
+}
+
+int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out) {
+  if (!geom_buffer || !out || P < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad argument");
+  GeomState g = GeomState::carve(geom_buffer, (size_t)P);
+  out->depths = g.depths;
+  out->radii = g.radii;
+  out->splats = reinterpret_cast<const float*>(g.splats);
+  out->cov3D = g.cov3D;
+  out->tiles_touched = g.tiles_touched;
+  out->point_offsets = g.point_offsets;
+  out->clamped = g.clamped;
+  return GSR_OK;
+}
+
+int gsr_binning_view_of(char* binning_buffer, int R, gsr_binning_view* out) {
+  if (!binning_buffer || !out || R < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad argument");
+  BinningState b = BinningState::carve(binning_buffer, (size_t)R);
+  out->keys_unsorted = nullptr;  // not kept: the sort ping-pongs over the unsorted pairs
+  out->values_unsorted = nullptr;
+  out->keys = b.keysA;
+  out->point_list = b.point_list;
+  return GSR_OK;
+}
+
+int gsr_image_view_of(char* image_buffer, int width, int height, gsr_image_view* out) {
+  if (!image_buffer || !out || width <= 0 || height <= 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad argument");
+  ImageState im = ImageState::carve(image_buffer, width, height);
+  out->ranges = reinterpret_cast<const uint32_t*>(im.ranges);
+  out->final_T = im.final_T;
+  out->n_contrib = im.n_contrib;
+  return GSR_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,171 @@
+// gsr_internal.hpp -- state layouts and stage launchers shared by the HIP translation units
+// of libgsraster_hip.so (gfx950 only).  Not part of the public ABI (include/gsraster.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace gsr {
+
+constexpr int TILE = 16;             // tile edge in pixels (reference: config.h:16-17)
+constexpr int SPLAT_F4 = 3;          // float4s per splat record (48 B)
+constexpr int GRAD_F4 = 3;           // float4s per per-instance gradient record (9 used of 12 floats)
+constexpr int PRE_BLOCK = 256;       // threads per block of the per-Gaussian kernels
+constexpr int SORT_TILE = 1024;      // keys per wave-tile of the radix sort (64 lanes x 16)
+constexpr int SORT_CHUNK = 64;       // wave-tiles per scan chunk
+constexpr size_t ALIGN = 256;
+
+inline size_t align_up(size_t v) { return (v + ALIGN - 1) & ~(ALIGN - 1); }
+
+// Bump carver over an opaque blob; with base == nullptr it only measures (the same trick as
+// the reference's required<T>(), rasterizer_impl.h:62-67).
+struct Carver {
+  char* base;
+  size_t off = 0;
+  explicit Carver(char* b) : base(b) {}
+  template <typename T>
+  T* take(size_t count) {
+    off = align_up(off);
+    T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+    off += count * sizeof(T);
+    return p;
+  }
+};
+
+// Per-Gaussian state (replaces GeometryState, rasterizer_impl.cu:137-151).  The splat record packs
+// everything the blend kernels need about one Gaussian into 48 contiguous bytes so a tile's list
+// is gathered with three 16-B loads per instance:
+//   f4[0] = (x, y, conic.x, conic.y)  f4[1] = (conic.z, opacity, r, g)  f4[2] = (b, depth, hx, hy)
+// hx/hy: half-extents (pixels) of a box that contains every pixel the splat can contribute to
+// (alpha >= 1/255), used for exact-conservative culling of 8x8 pixel quads.
+struct GeomState {
+  float* depths;
+  int32_t* radii;
+  float4* splats;
+  float* cov3D;
+  uint32_t* tiles_touched;
+  uint32_t* point_offsets;  // inclusive scan of tiles_touched
+  uint8_t* clamped;         // bit0..2
+  uint32_t* block_sums;     // per 256-Gaussian block: sum of tiles_touched, then exclusive offsets
+  uint32_t* total;          // [1] num_rendered, device side
+  uint2* slotinfo;          // {first slot (exclusive offset), x0 | y0 << 10 | rect_width << 20} per visible Gaussian
+  static GeomState carve(char* blob, size_t P, size_t* bytes = nullptr) {
+    Carver c(blob);
+    GeomState g;
+    size_t nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+    g.depths = c.take<float>(P);
+    g.radii = c.take<int32_t>(P);
+    g.splats = c.take<float4>(P * SPLAT_F4);
+    g.cov3D = c.take<float>(P * 6);
+    g.tiles_touched = c.take<uint32_t>(P);
+    g.point_offsets = c.take<uint32_t>(P);
+    g.clamped = c.take<uint8_t>(P);
+    g.block_sums = c.take<uint32_t>(nb + 1);
+    g.total = c.take<uint32_t>(64);
+    g.slotinfo = c.take<uint2>(P);
+    if (bytes) *bytes = align_up(c.off) + ALIGN;
+    return g;
+  }
+};
+
+// Per-image state (replaces ImageState, rasterizer_impl.cu:153-159).
+struct ImageState {
+  uint2* ranges;        // [tiles]
+  uint32_t* tile_last;  // [tiles] max n_contrib over the tile's pixels (bounds the backward walk)
+  float* final_T;       // [H*W]
+  uint32_t* n_contrib;  // [H*W]
+  static ImageState carve(char* blob, int W, int H, size_t* bytes = nullptr) {
+    Carver c(blob);
+    ImageState s;
+    size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
+    size_t N = (size_t)W * H;
+    s.ranges = c.take<uint2>(tiles);
+    s.tile_last = c.take<uint32_t>(tiles);
+    s.final_T = c.take<float>(N);
+    s.n_contrib = c.take<uint32_t>(N);
+    if (bytes) *bytes = align_up(c.off) + ALIGN;
+    return s;
+  }
+};
+
+// Per-instance state (replaces BinningState, rasterizer_impl.cu:161-177).  The sort ping-pongs
+// between (keysA, point_list) and (keysB, valsB); the final pass always lands in keysA/point_list.
+// After the forward only point_list is live, so the backward's per-instance gradient records
+// (grad_inst, 48 B each, indexed by UNSORTED slot = the Gaussian's contiguous run) alias the
+// sort buffers.
+struct BinningState {
+  uint32_t* point_list;
+  uint64_t* keysA;
+  uint64_t* keysB;
+  uint32_t* valsB;
+  uint32_t* counts;      // [ntiles][256] per wave-tile digit counts -> exclusive in-chunk prefixes
+  uint32_t* chunk_sums;  // [nchunks][256] -> exclusive chunk bases
+  uint32_t* digit_base;  // [256]
+  float4* grad_inst;     // [R][3], aliases keysA..counts
+  uint8_t* inst_flag;    // [R] 1 = grad_inst[slot] was written by the blend backward
+  static BinningState carve(char* blob, size_t R, size_t* bytes = nullptr) {
+    Carver c(blob);
+    BinningState b;
+    size_t ntiles = (R + SORT_TILE - 1) / SORT_TILE;
+    size_t nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
+    b.point_list = c.take<uint32_t>(R);
+    size_t mark = align_up(c.off);
+    b.keysA = c.take<uint64_t>(R);
+    b.keysB = c.take<uint64_t>(R);
+    b.valsB = c.take<uint32_t>(R);
+    b.counts = c.take<uint32_t>(ntiles * 256);
+    b.chunk_sums = c.take<uint32_t>(nchunks * 256);
+    b.digit_base = c.take<uint32_t>(256);
+    size_t sort_end = c.off;
+    Carver g(blob);
+    g.off = mark;
+    b.grad_inst = g.take<float4>(R * GRAD_F4);
+    c.off = sort_end > g.off ? sort_end : g.off;
+    b.inst_flag = c.take<uint8_t>(R);
+    if (bytes) *bytes = align_up(c.off) + ALIGN;
+    return b;
+  }
+};
+
+struct FrameParams {
+  int P, D, M, W, H, gx, gy;
+  float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+};
+
+// ---- stage launchers (each enqueues on `s`; returns hipGetLastError()) ----
+hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const float* scales, const float* rotations,
+                             const float* opacities, const float* shs, const float* cov3D_precomp,
+                             const float* colors_precomp, const float* view, const float* proj, const float* campos,
+                             GeomState g, int* radii_out, hipStream_t s);
+hipError_t launch_scan_block_sums(GeomState g, int P, hipStream_t s);
+hipError_t launch_duplicate(const FrameParams& fp, GeomState g, uint64_t* keys_out, uint32_t* vals_out, hipStream_t s);
+hipError_t launch_sort_pairs(BinningState b, int R, int end_bit, bool start_in_A, hipStream_t s);
+hipError_t launch_tile_ranges(const uint64_t* keys, int R, uint2* ranges, int tiles, hipStream_t s);
+hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
+                                float* out_color, float* out_depth, float* out_acc, hipStream_t s);
+hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
+                                 const float* dL_dpix, const float* dL_dacc, hipStream_t s);
+hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningState b, const int* radii,
+                                    const float* means3D, const float* scales, const float* rotations,
+                                    const float* shs, const float* cov3D_used, const float* view, const float* proj,
+                                    const float* campos, bool colors_precomp, float* dL_dmean2D, float* dL_dconic,
+                                    float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                                    float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
+hipError_t launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
+
+inline int sort_passes(int end_bit) { return (end_bit + 7) / 8; }
+
+// getRect (reference auxiliary.h:39-46): tile rectangle [x0,x1) x [y0,y1) touched by a splat of
+// integer pixel radius `radius` centred at (px,py); float arithmetic with truncating casts, exactly
+// as the reference so the rectangle (and hence every sort key) matches bit for bit.  Only
+// add/sub and a division by 16 are involved, so FMA contraction cannot change the result.
+__host__ __device__ inline void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1,
+                                          int& y1) {
+  const float r = (float)radius;
+  int a = (int)((px - r) / 16.0f), b = (int)((py - r) / 16.0f);
+  int c = (int)((((px + r) + 16.0f) - 1.0f) / 16.0f), d = (int)((((py + r) + 16.0f) - 1.0f) / 16.0f);
+  a = a < 0 ? 0 : a; b = b < 0 ? 0 : b; c = c < 0 ? 0 : c; d = d < 0 ? 0 : d;
+  x0 = a > gx ? gx : a; y0 = b > gy ? gy : b; x1 = c > gx ? gx : c; y1 = d > gy ? gy : d;
+}
+
+}  // namespace gsr

@@ -1,0 +1,593 @@
+// preprocess.hip -- per-Gaussian stages of the MI355X rasterizer (gfx950):
+//   F1  k_preprocess        project / cull / EWA / SH->RGB, pack 48-B splat records, per-block tile sums
+//   F2  k_scan_block_sums   exclusive scan of the per-block sums (+ total = num_rendered)
+//   F4  k_duplicate         in-block scan -> point_offsets, emit (tile|depth) keys + Gaussian ids
+//   B2+B3 k_gaussian_backward  sum the per-instance gradient records of each Gaussian (no atomics,
+//        fixed order) and run the EWA / projection / SH / covariance chain rule in the same pass
+//   V1  k_mark_visible
+//
+// THIS FILE IS COMPILED WITH -ffp-contract=off.  radii, tile rectangles and the depth bits of the
+// sort keys are exact-match targets: every f32 operation below that feeds them is written in the
+// evaluation order of the reference (GLM column-major products, accumulated left to right) so the
+// rounding matches the unfused CPU oracle bit for bit.  Divisions and sqrt are IEEE (hipcc default
+// -fhip-fp32-correctly-rounded-divide-sqrt).
+#include "gsr_internal.hpp"
+
+namespace gsr {
+
+// CUDA's min/max on floats are fminf/fmaxf (NaN-ignoring); v_min_f32/v_max_f32 have the same semantics.
+__device__ __forceinline__ float fmin_(float a, float b) { return fminf(a, b); }
+__device__ __forceinline__ float fmax_(float a, float b) { return fmaxf(a, b); }
+
+// ndc2Pix (reference auxiliary.h:35-37) is evaluated in f64 there (double literals) and rounded once.
+__device__ __forceinline__ float ndc_to_pix(float v, int S) {
+  return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
+}
+
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Inclusive scan across the 64 lanes of a wave.
+__device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    uint32_t t = __shfl_up(v, o, 64);
+    if (lane >= o) v += t;
+  }
+  return v;
+}
+
+constexpr float SH0 = 0.28209479177387814f;
+constexpr float SH1 = 0.4886025119029199f;
+__device__ const float SH2c[5] = {1.0925484305920792f, -1.0925484305920792f, 0.31539156525252005f,
+                                  -1.0925484305920792f, 0.5462742152960396f};
+__device__ const float SH3c[7] = {-0.5900435899266435f, 2.890611442640554f, -0.4570457994644658f, 0.3731763325901154f,
+                                  -0.4570457994644658f, 1.445305721320277f,  -0.5900435899266435f};
+
+// Symmetric 3D covariance (6 floats) from scale and quaternion (r,x,y,z), used as given.
+// Restates forward.cu:138-176: M = S*R (column-major), Sigma = M^T M.
+__device__ __forceinline__ void cov3d_from_scale_rot(const float s0, const float s1, const float s2, const float4 q,
+                                                     float* c6) {
+  const float r = q.x, x = q.y, y = q.z, z = q.w;
+  // R[c][r]: column c, row r
+  const float R00 = 1.f - 2.f * (y * y + z * z), R01 = 2.f * (x * y - r * z), R02 = 2.f * (x * z + r * y);
+  const float R10 = 2.f * (x * y + r * z), R11 = 1.f - 2.f * (x * x + z * z), R12 = 2.f * (y * z - r * x);
+  const float R20 = 2.f * (x * z - r * y), R21 = 2.f * (y * z + r * x), R22 = 1.f - 2.f * (x * x + y * y);
+  // M[c][r] = s_r * R[c][r]
+  const float M00 = s0 * R00, M01 = s1 * R01, M02 = s2 * R02;
+  const float M10 = s0 * R10, M11 = s1 * R11, M12 = s2 * R12;
+  const float M20 = s0 * R20, M21 = s1 * R21, M22 = s2 * R22;
+  // Sigma[c][r] = M[r][0]*M[c][0] + M[r][1]*M[c][1] + M[r][2]*M[c][2]
+  c6[0] = M00 * M00 + M01 * M01 + M02 * M02;  // Sigma[0][0]
+  c6[1] = M10 * M00 + M11 * M01 + M12 * M02;  // Sigma[0][1]
+  c6[2] = M20 * M00 + M21 * M01 + M22 * M02;  // Sigma[0][2]
+  c6[3] = M10 * M10 + M11 * M11 + M12 * M12;  // Sigma[1][1]
+  c6[4] = M20 * M10 + M21 * M11 + M22 * M12;  // Sigma[1][2]
+  c6[5] = M20 * M20 + M21 * M21 + M22 * M22;  // Sigma[2][2]
+}
+
+struct Ewa {
+  float T00, T01, T02, T10, T11, T12;  // T[c][r] for c = 0,1 (third column is zero)
+  float tx, ty, tz, txtz, tytz;
+  float cxx, cxy, cyy;  // cov2D before the +0.3 low-pass
+};
+
+// Restates forward.cu:79-126 / backward.cu:159-200: T = W*J, cov = T^T Vrk^T T.
+__device__ __forceinline__ Ewa ewa_project(const float mx, const float my, const float mz, const FrameParams& fp,
+                                           const float* __restrict__ c6, const float* __restrict__ V) {
+  Ewa e;
+  float t0 = V[0] * mx + V[4] * my + V[8] * mz + V[12];
+  float t1 = V[1] * mx + V[5] * my + V[9] * mz + V[13];
+  const float t2 = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+  const float limx = 1.3f * fp.tan_fovx, limy = 1.3f * fp.tan_fovy;
+  e.txtz = t0 / t2;
+  e.tytz = t1 / t2;
+  t0 = fmin_(limx, fmax_(-limx, e.txtz)) * t2;
+  t1 = fmin_(limy, fmax_(-limy, e.tytz)) * t2;
+  e.tx = t0; e.ty = t1; e.tz = t2;
+  const float J00 = fp.focal_x / t2, J02 = -(fp.focal_x * t0) / (t2 * t2);
+  const float J11 = fp.focal_y / t2, J12 = -(fp.focal_y * t1) / (t2 * t2);
+  // W[k][r] = V[k + 4r];  T[0][r] = W[0][r]*J00 + W[2][r]*J02;  T[1][r] = W[1][r]*J11 + W[2][r]*J12
+  e.T00 = V[0] * J00 + V[2] * J02;
+  e.T01 = V[4] * J00 + V[6] * J02;
+  e.T02 = V[8] * J00 + V[10] * J02;
+  e.T10 = V[1] * J11 + V[2] * J12;
+  e.T11 = V[5] * J11 + V[6] * J12;
+  e.T12 = V[9] * J11 + V[10] * J12;
+  // A[c][r] = T[r][0]*S(0,c) + T[r][1]*S(1,c) + T[r][2]*S(2,c), S symmetric from c6
+  const float S00 = c6[0], S01 = c6[1], S02 = c6[2], S11 = c6[3], S12 = c6[4], S22 = c6[5];
+  const float A00 = e.T00 * S00 + e.T01 * S01 + e.T02 * S02;
+  const float A10 = e.T00 * S01 + e.T01 * S11 + e.T02 * S12;
+  const float A20 = e.T00 * S02 + e.T01 * S12 + e.T02 * S22;
+  const float A01 = e.T10 * S00 + e.T11 * S01 + e.T12 * S02;
+  const float A11 = e.T10 * S01 + e.T11 * S11 + e.T12 * S12;
+  const float A21 = e.T10 * S02 + e.T11 * S12 + e.T12 * S22;
+  e.cxx = A00 * e.T00 + A10 * e.T01 + A20 * e.T02;  // cov[0][0]
+  e.cxy = A01 * e.T00 + A11 * e.T01 + A21 * e.T02;  // cov[0][1]
+  e.cyy = A01 * e.T10 + A11 * e.T11 + A21 * e.T12;  // cov[1][1]
+  return e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F1.  One thread per Gaussian.  Replaces preprocessCUDA (reference forward.cu:179-286).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
+    const FrameParams fp, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
+    const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
+    const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos, GeomState g,
+    int* __restrict__ radii_out) {
+  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  uint32_t tiles = 0;
+  int radius = 0;
+  if (idx < fp.P) {
+    const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+    const float pvz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+    bool alive = !(pvz <= 0.2f);  // near cull only (forward.cu:221-225)
+    float s0 = 0, s1 = 0, s2 = 0;
+    if (alive && scales) {  // scale cull (forward.cu:19-25)
+      s0 = fp.scale_modifier * scales[3 * idx];
+      s1 = fp.scale_modifier * scales[3 * idx + 1];
+      s2 = fp.scale_modifier * scales[3 * idx + 2];
+      alive = !(s0 > 0.3f || s1 > 0.3f || s2 > 0.3f);
+    }
+    if (alive) {
+      const float ph0 = Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12];
+      const float ph1 = Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13];
+      const float ph3 = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
+      const float pw = 1.0f / (ph3 + 0.0000001f);
+      const float ppx = ph0 * pw, ppy = ph1 * pw;
+      float c6[6];
+      if (cov3D_precomp) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * idx + k];
+      } else {
+        cov3d_from_scale_rot(s0, s1, s2, reinterpret_cast<const float4*>(rotations)[idx], c6);
+#pragma unroll
+        for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)idx + k] = c6[k];
+      }
+      const Ewa e = ewa_project(mx, my, mz, fp, c6, V);
+      const float cx = e.cxx + 0.3f, cy = e.cxy, cz = e.cyy + 0.3f;
+      const float det = cx * cz - cy * cy;
+      if (det != 0.0f) {
+        const float det_inv = 1.f / det;
+        const float conx = cz * det_inv, cony = -cy * det_inv, conz = cx * det_inv;
+        const float mid = 0.5f * (cx + cz);
+        const float disc = sqrtf(fmax_(0.1f, mid * mid - det));
+        const float lambda1 = mid + disc, lambda2 = mid - disc;
+        const float my_radius = ceilf(3.f * sqrtf(fmax_(lambda1, lambda2)));
+        const float pixx = ndc_to_pix(ppx, fp.W), pixy = ndc_to_pix(ppy, fp.H);
+        int x0, y0, x1, y1;
+        tile_rect(pixx, pixy, (int)my_radius, fp.gx, fp.gy, x0, y0, x1, y1);
+        const int area = (x1 - x0) * (y1 - y0);
+        if (area != 0) {
+          float rgb[3];
+          uint8_t clampbits = 0;
+          if (colors_precomp) {
+            rgb[0] = colors_precomp[3 * idx];
+            rgb[1] = colors_precomp[3 * idx + 1];
+            rgb[2] = colors_precomp[3 * idx + 2];
+          } else {  // SH -> RGB (forward.cu:29-76)
+            const float d0 = mx - campos[0], d1 = my - campos[1], d2 = mz - campos[2];
+            const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+            const float x = d0 / len, y = d1 / len, z = d2 / len;
+            const float* sh = shs + (size_t)idx * fp.M * 3;
+#pragma unroll
+            for (int ch = 0; ch < 3; ch++) {
+              float res = SH0 * sh[ch];
+              if (fp.D > 0) {
+                res = res - SH1 * y * sh[3 + ch] + SH1 * z * sh[6 + ch] - SH1 * x * sh[9 + ch];
+                if (fp.D > 1) {
+                  const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+                  res = res + SH2c[0] * xy * sh[12 + ch] + SH2c[1] * yz * sh[15 + ch] +
+                        SH2c[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + SH2c[3] * xz * sh[21 + ch] +
+                        SH2c[4] * (xx - yy) * sh[24 + ch];
+                  if (fp.D > 2) {
+                    res = res + SH3c[0] * y * (3.0f * xx - yy) * sh[27 + ch] + SH3c[1] * xy * z * sh[30 + ch] +
+                          SH3c[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
+                          SH3c[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
+                          SH3c[4] * x * (4.0f * zz - xx - yy) * sh[39 + ch] + SH3c[5] * z * (xx - yy) * sh[42 + ch] +
+                          SH3c[6] * x * (xx - 3.0f * yy) * sh[45 + ch];
+                  }
+                }
+              }
+              res += 0.5f;
+              if (res < 0) clampbits |= (uint8_t)(1u << ch);
+              rgb[ch] = fmax_(res, 0.0f);
+            }
+          }
+          const float op = opacities[idx];
+          // Exact-conservative footprint: a pixel can only receive alpha = min(.99, op*exp(power)) >= 1/255
+          // if -power <= ln(255*op); the axis-aligned box of that ellipse (plus slack for rounding in
+          // the blend kernels) bounds every contributing pixel.  op < 1/255 never contributes.
+          float hx, hy;
+          if (op < 1.0f / 255.0f) {
+            hx = hy = -1e30f;  // box test can never pass
+          } else {
+            const float tau = __logf(255.0f * op) * 1.01f + 0.02f;
+            const float dc = conx * conz - cony * cony;
+            if (conx > 0.0f && conz > 0.0f && dc > 0.0f) {
+              hx = sqrtf(2.0f * tau * conz / dc) + 0.05f;
+              hy = sqrtf(2.0f * tau * conx / dc) + 0.05f;
+            } else {
+              hx = hy = 1e30f;  // indefinite conic: no culling
+            }
+          }
+          radius = (int)my_radius;
+          tiles = (uint32_t)area;
+          g.depths[idx] = pvz;
+          float4* rec = g.splats + (size_t)idx * SPLAT_F4;
+          rec[0] = make_float4(pixx, pixy, conx, cony);
+          rec[1] = make_float4(conz, op, rgb[0], rgb[1]);
+          rec[2] = make_float4(rgb[2], pvz, hx, hy);
+          g.clamped[idx] = clampbits;
+        }
+      }
+    }
+    g.radii[idx] = radius;
+    if (radii_out) radii_out[idx] = radius;
+    g.tiles_touched[idx] = tiles;
+  }
+  // per-block sum of tiles_touched -> block_sums[blockIdx.x]
+  __shared__ uint32_t wsum[PRE_BLOCK / 64];
+  const uint32_t ws = wave_sum_u32(tiles);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) g.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// F2.  One workgroup: exclusive scan of block_sums[nb] in place, total -> g.total[0].
+// Together with the in-block scan in k_duplicate this is cub::DeviceScan::InclusiveSum
+// (reference rasterizer_impl.cu:270-273).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, int nb,
+                                                          uint32_t* __restrict__ total) {
+  __shared__ uint32_t wtot[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int base = 0; base < nb; base += 1024) {
+    const int i = base + tid;
+    const uint32_t v = i < nb ? sums[i] : 0u;
+    const uint32_t inc = wave_incl_scan_u32(v, lane);
+    if (lane == 63) wtot[w] = inc;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (int k = 0; k < w; k++) woff += wtot[k];
+    const uint32_t carry = carry_s;
+    if (i < nb) sums[i] = carry + woff + inc - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + inc;
+    __syncthreads();
+  }
+  if (tid == 0) total[0] = carry_s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// F4.  Replaces duplicateWithKeys (reference rasterizer_impl.cu:64-101).  Each block re-derives its
+// Gaussians' write offsets from block_sums (exclusive) + an in-block scan, stores the inclusive
+// point_offsets, and emits key = (tile << 32) | bits(depth), value = Gaussian id, in row-major tile
+// order.  The slot of an instance (offset_exclusive + index inside the rect) is also the index of
+// its gradient record in the backward.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_BLOCK) void k_duplicate(const FrameParams fp, GeomState g,
+                                                         uint64_t* __restrict__ keys_out,
+                                                         uint32_t* __restrict__ vals_out) {
+  __shared__ uint32_t wtot[PRE_BLOCK / 64];
+  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t n = idx < fp.P ? g.tiles_touched[idx] : 0u;
+  const uint32_t inc = wave_incl_scan_u32(n, lane);
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();
+  uint32_t off = g.block_sums[blockIdx.x];
+  for (int k = 0; k < w; k++) off += wtot[k];
+  off += inc;  // inclusive
+  if (idx < fp.P) g.point_offsets[idx] = off;
+  if (n == 0) return;
+  off -= n;
+  const float4 r0 = g.splats[(size_t)idx * SPLAT_F4];
+  int x0, y0, x1, y1;
+  tile_rect(r0.x, r0.y, g.radii[idx], fp.gx, fp.gy, x0, y0, x1, y1);
+  const uint64_t dbits = (uint64_t)__float_as_uint(g.depths[idx]);
+  g.slotinfo[idx] = make_uint2(off, (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20));
+  for (int y = y0; y < y1; y++)
+    for (int x = x0; x < x1; x++) {
+      keys_out[off] = ((uint64_t)(uint32_t)(y * fp.gx + x) << 32) | dbits;
+      vals_out[off] = (uint32_t)idx;
+      off++;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B2 + B3, fused with the gradient gather.  One thread per Gaussian.  Replaces computeCov2DCUDA
+// (reference backward.cu:140-275), preprocessCUDA backward (:371-435), computeColorFromSH backward
+// (:20-135) and computeCov3D backward (:279-366), and the 9 atomicAdds per (pixel, Gaussian) of the
+// reference's blend backward (:565,591-600): the blend backward left one 9-float record per
+// (tile, Gaussian) instance in the Gaussian's contiguous slot run; they are summed here in slot
+// order, which makes the whole backward bitwise reproducible.
+// Every output element of Gaussian idx is written (zeros when radii <= 0).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
+    const FrameParams fp, GeomState g, const float4* __restrict__ grad_inst, const uint8_t* __restrict__ inst_flag,
+    const int* __restrict__ radii, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ cov3D_used,
+    const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos,
+    const int colors_are_precomp, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
+    float* __restrict__ dL_drot) {
+  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  if (idx >= fp.P) return;
+  const bool vis = radii[idx] > 0;
+  // ---- gather-sum of the instance records ----
+  float gcol0 = 0, gcol1 = 0, gcol2 = 0, gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
+  if (vis) {
+    const uint32_t n = g.tiles_touched[idx];
+    const uint32_t first = g.point_offsets[idx] - n;
+    for (uint32_t k = 0; k < n; k++) {
+      const size_t slot = (size_t)first + k;
+      if (inst_flag[slot]) {
+        const float4 a = grad_inst[slot * GRAD_F4 + 0];
+        const float4 b = grad_inst[slot * GRAD_F4 + 1];
+        const float4 c = grad_inst[slot * GRAD_F4 + 2];
+        gcol0 += a.x; gcol1 += a.y; gcol2 += a.z; gmx += a.w;
+        gmy += b.x; gca += b.y; gcb += b.z; gcc += b.w;
+        gop += c.x;
+      }
+    }
+  }
+  dL_dmean2D[3 * idx] = gmx; dL_dmean2D[3 * idx + 1] = gmy; dL_dmean2D[3 * idx + 2] = 0.f;
+  dL_dconic[4 * idx] = gca; dL_dconic[4 * idx + 1] = gcb; dL_dconic[4 * idx + 2] = 0.f; dL_dconic[4 * idx + 3] = gcc;
+  dL_dopacity[idx] = gop;
+  dL_dcolor[3 * idx] = gcol0; dL_dcolor[3 * idx + 1] = gcol1; dL_dcolor[3 * idx + 2] = gcol2;
+  const int M = fp.M;
+  if (!vis) {
+    dL_dmean3D[3 * idx] = 0.f; dL_dmean3D[3 * idx + 1] = 0.f; dL_dmean3D[3 * idx + 2] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = 0.f;
+    for (int k = 0; k < 3 * M; k++) dL_dsh[(size_t)idx * M * 3 + k] = 0.f;
+    dL_dscale[3 * idx] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f;
+    dL_drot[4 * idx] = 0.f; dL_drot[4 * idx + 1] = 0.f; dL_drot[4 * idx + 2] = 0.f; dL_drot[4 * idx + 3] = 0.f;
+    return;
+  }
+  const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+  // ---- B2: conic -> cov2D -> cov3D and mean (backward.cu:140-275) ----
+  float c6[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) c6[k] = cov3D_used[6 * (size_t)idx + k];
+  const Ewa e = ewa_project(mx, my, mz, fp, c6, V);
+  const float limx = 1.3f * fp.tan_fovx, limy = 1.3f * fp.tan_fovy;
+  const float xmul = (e.txtz < -limx || e.txtz > limx) ? 0.f : 1.f;
+  const float ymul = (e.tytz < -limy || e.tytz > limy) ? 0.f : 1.f;
+  const float a = e.cxx + 0.3f, b = e.cxy, c = e.cyy + 0.3f;
+  const float denom = a * c - b * b;
+  float dL_da = 0, dL_db = 0, dL_dc = 0;
+  const float denom2inv = 1.0f / ((denom * denom) + 0.0000001f);
+  float dcov[6] = {0, 0, 0, 0, 0, 0};
+  if (denom2inv != 0) {
+    dL_da = denom2inv * (-c * c * gca + 2 * b * c * gcb + (denom - a * c) * gcc);
+    dL_dc = denom2inv * (-a * a * gcc + 2 * a * b * gcb + (denom - a * c) * gca);
+    dL_db = denom2inv * 2 * (b * c * gca - (denom + 2 * b * b) * gcb + a * b * gcc);
+    dcov[0] = (e.T00 * e.T00 * dL_da + e.T00 * e.T10 * dL_db + e.T10 * e.T10 * dL_dc);
+    dcov[3] = (e.T01 * e.T01 * dL_da + e.T01 * e.T11 * dL_db + e.T11 * e.T11 * dL_dc);
+    dcov[5] = (e.T02 * e.T02 * dL_da + e.T02 * e.T12 * dL_db + e.T12 * e.T12 * dL_dc);
+    dcov[1] = 2 * e.T00 * e.T01 * dL_da + (e.T00 * e.T11 + e.T01 * e.T10) * dL_db + 2 * e.T10 * e.T11 * dL_dc;
+    dcov[2] = 2 * e.T00 * e.T02 * dL_da + (e.T00 * e.T12 + e.T02 * e.T10) * dL_db + 2 * e.T10 * e.T12 * dL_dc;
+    dcov[4] = 2 * e.T02 * e.T01 * dL_da + (e.T01 * e.T12 + e.T02 * e.T11) * dL_db + 2 * e.T11 * e.T12 * dL_dc;
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = dcov[k];
+  // Vrk[c][r] symmetric: S(c,r)
+  const float S00 = c6[0], S01 = c6[1], S02 = c6[2], S11 = c6[3], S12 = c6[4], S22 = c6[5];
+  const float u0 = e.T00 * S00 + e.T01 * S01 + e.T02 * S02, u1 = e.T00 * S01 + e.T01 * S11 + e.T02 * S12,
+              u2 = e.T00 * S02 + e.T01 * S12 + e.T02 * S22;
+  const float v0 = e.T10 * S00 + e.T11 * S01 + e.T12 * S02, v1 = e.T10 * S01 + e.T11 * S11 + e.T12 * S12,
+              v2 = e.T10 * S02 + e.T11 * S12 + e.T12 * S22;
+  const float dT00 = 2 * u0 * dL_da + v0 * dL_db, dT01 = 2 * u1 * dL_da + v1 * dL_db, dT02 = 2 * u2 * dL_da + v2 * dL_db;
+  const float dT10 = 2 * v0 * dL_dc + u0 * dL_db, dT11 = 2 * v1 * dL_dc + u1 * dL_db, dT12 = 2 * v2 * dL_dc + u2 * dL_db;
+  // W[k][r] = V[k + 4r]
+  const float dJ00 = V[0] * dT00 + V[4] * dT01 + V[8] * dT02;
+  const float dJ02 = V[2] * dT00 + V[6] * dT01 + V[10] * dT02;
+  const float dJ11 = V[1] * dT10 + V[5] * dT11 + V[9] * dT12;
+  const float dJ12 = V[2] * dT10 + V[6] * dT11 + V[10] * dT12;
+  const float tz = 1.f / e.tz, tz2 = tz * tz, tz3 = tz2 * tz;
+  const float hx = fp.focal_x, hy = fp.focal_y;
+  const float dtx = xmul * -hx * tz2 * dJ02;
+  const float dty = ymul * -hy * tz2 * dJ12;
+  const float dtz = -hx * tz2 * dJ00 - hy * tz2 * dJ11 + (2 * hx * e.tx) * tz3 * dJ02 + (2 * hy * e.ty) * tz3 * dJ12;
+  float dm0 = V[0] * dtx + V[1] * dty + V[2] * dtz;
+  float dm1 = V[4] * dtx + V[5] * dty + V[6] * dtz;
+  float dm2 = V[8] * dtx + V[9] * dty + V[10] * dtz;
+  // ---- B3: projection Jacobian (backward.cu:389-407) ----
+  {
+    const float mh3 = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
+    const float m_w = 1.0f / (mh3 + 0.0000001f);
+    const float mul1 = (Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12]) * m_w * m_w;
+    const float mul2 = (Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13]) * m_w * m_w;
+    dm0 += (Pm[0] * m_w - Pm[3] * mul1) * gmx + (Pm[1] * m_w - Pm[3] * mul2) * gmy;
+    dm1 += (Pm[4] * m_w - Pm[7] * mul1) * gmx + (Pm[5] * m_w - Pm[7] * mul2) * gmy;
+    dm2 += (Pm[8] * m_w - Pm[11] * mul1) * gmx + (Pm[9] * m_w - Pm[11] * mul2) * gmy;
+  }
+  // ---- SH backward (backward.cu:20-135) ----
+  if (shs && !colors_are_precomp) {
+    const uint8_t cb = g.clamped[idx];
+    const float gr[3] = {(cb & 1) ? 0.f : gcol0, (cb & 2) ? 0.f : gcol1, (cb & 4) ? 0.f : gcol2};
+    const float q0 = mx - campos[0], q1 = my - campos[1], q2 = mz - campos[2];
+    const float len = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
+    const float x = q0 / len, y = q1 / len, z = q2 / len;
+    const float* sh = shs + (size_t)idx * M * 3;
+    float* gs = dL_dsh + (size_t)idx * M * 3;
+    float ddx = 0, ddy = 0, ddz = 0;  // dL_ddir
+    const int D = fp.D;
+#pragma unroll
+    for (int ch = 0; ch < 3; ch++) {
+      const float gch = gr[ch];
+      float dx_ = 0, dy_ = 0, dz_ = 0;  // dRGB/d{x,y,z} for this channel
+      gs[ch] = SH0 * gch;
+      if (D > 0) {
+        gs[3 + ch] = (-SH1 * y) * gch;
+        gs[6 + ch] = (SH1 * z) * gch;
+        gs[9 + ch] = (-SH1 * x) * gch;
+        dx_ = -SH1 * sh[9 + ch];
+        dy_ = -SH1 * sh[3 + ch];
+        dz_ = SH1 * sh[6 + ch];
+        if (D > 1) {
+          const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+          gs[12 + ch] = (SH2c[0] * xy) * gch;
+          gs[15 + ch] = (SH2c[1] * yz) * gch;
+          gs[18 + ch] = (SH2c[2] * (2.f * zz - xx - yy)) * gch;
+          gs[21 + ch] = (SH2c[3] * xz) * gch;
+          gs[24 + ch] = (SH2c[4] * (xx - yy)) * gch;
+          dx_ += SH2c[0] * y * sh[12 + ch] + SH2c[2] * 2.f * -x * sh[18 + ch] + SH2c[3] * z * sh[21 + ch] +
+                 SH2c[4] * 2.f * x * sh[24 + ch];
+          dy_ += SH2c[0] * x * sh[12 + ch] + SH2c[1] * z * sh[15 + ch] + SH2c[2] * 2.f * -y * sh[18 + ch] +
+                 SH2c[4] * 2.f * -y * sh[24 + ch];
+          dz_ += SH2c[1] * y * sh[15 + ch] + SH2c[2] * 2.f * 2.f * z * sh[18 + ch] + SH2c[3] * x * sh[21 + ch];
+          if (D > 2) {
+            gs[27 + ch] = (SH3c[0] * y * (3.f * xx - yy)) * gch;
+            gs[30 + ch] = (SH3c[1] * xy * z) * gch;
+            gs[33 + ch] = (SH3c[2] * y * (4.f * zz - xx - yy)) * gch;
+            gs[36 + ch] = (SH3c[3] * z * (2.f * zz - 3.f * xx - 3.f * yy)) * gch;
+            gs[39 + ch] = (SH3c[4] * x * (4.f * zz - xx - yy)) * gch;
+            gs[42 + ch] = (SH3c[5] * z * (xx - yy)) * gch;
+            gs[45 + ch] = (SH3c[6] * x * (xx - 3.f * yy)) * gch;
+            dx_ += (SH3c[0] * sh[27 + ch] * 3.f * 2.f * xy + SH3c[1] * sh[30 + ch] * yz +
+                    SH3c[2] * sh[33 + ch] * -2.f * xy + SH3c[3] * sh[36 + ch] * -3.f * 2.f * xz +
+                    SH3c[4] * sh[39 + ch] * (-3.f * xx + 4.f * zz - yy) + SH3c[5] * sh[42 + ch] * 2.f * xz +
+                    SH3c[6] * sh[45 + ch] * 3.f * (xx - yy));
+            dy_ += (SH3c[0] * sh[27 + ch] * 3.f * (xx - yy) + SH3c[1] * sh[30 + ch] * xz +
+                    SH3c[2] * sh[33 + ch] * (-3.f * yy + 4.f * zz - xx) + SH3c[3] * sh[36 + ch] * -3.f * 2.f * yz +
+                    SH3c[4] * sh[39 + ch] * -2.f * xy + SH3c[5] * sh[42 + ch] * -2.f * yz +
+                    SH3c[6] * sh[45 + ch] * -3.f * 2.f * xy);
+            dz_ += (SH3c[1] * sh[30 + ch] * xy + SH3c[2] * sh[33 + ch] * 4.f * 2.f * yz +
+                    SH3c[3] * sh[36 + ch] * 3.f * (2.f * zz - xx - yy) + SH3c[4] * sh[39 + ch] * 4.f * 2.f * xz +
+                    SH3c[5] * sh[42 + ch] * (xx - yy));
+          }
+        }
+      }
+      ddx += dx_ * gch;
+      ddy += dy_ * gch;
+      ddz += dz_ * gch;
+    }
+    // coefficients beyond the active degree get zero gradient
+    const int used = (D + 1) * (D + 1);
+    for (int k = used * 3; k < M * 3; k++) gs[k] = 0.f;
+    const float sum2 = q0 * q0 + q1 * q1 + q2 * q2;
+    const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
+    dm0 += ((+sum2 - q0 * q0) * ddx - q1 * q0 * ddy - q2 * q0 * ddz) * inv32;
+    dm1 += (-q0 * q1 * ddx + (sum2 - q1 * q1) * ddy - q2 * q1 * ddz) * inv32;
+    dm2 += (-q0 * q2 * ddx - q1 * q2 * ddy + (sum2 - q2 * q2) * ddz) * inv32;
+  } else {
+    for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)idx * M * 3 + k] = 0.f;
+  }
+  dL_dmean3D[3 * idx] = dm0; dL_dmean3D[3 * idx + 1] = dm1; dL_dmean3D[3 * idx + 2] = dm2;
+  // ---- covariance -> scale / rotation (backward.cu:279-366) ----
+  if (scales) {
+    const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+    const float r = q.x, x = q.y, y = q.z, z = q.w;
+    const float s[3] = {fp.scale_modifier * scales[3 * idx], fp.scale_modifier * scales[3 * idx + 1],
+                        fp.scale_modifier * scales[3 * idx + 2]};
+    float R[3][3];  // R[c][r]
+    R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
+    R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
+    R[2][0] = 2.f * (x * z - r * y); R[2][1] = 2.f * (y * z + r * x); R[2][2] = 1.f - 2.f * (x * x + y * y);
+    // dSig[c][r]
+    const float dS[3][3] = {{dcov[0], 0.5f * dcov[1], 0.5f * dcov[2]},
+                            {0.5f * dcov[1], dcov[3], 0.5f * dcov[4]},
+                            {0.5f * dcov[2], 0.5f * dcov[4], dcov[5]}};
+    // dM = (2*M) * dSig, M[c][r] = s_r R[c][r];  dM[c][r] = sum_k 2M[k][r] * dS[c][k]
+    float dMt[3][3];  // dMt[c][r] = dM[r][c]
+#pragma unroll
+    for (int cc = 0; cc < 3; cc++)
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++) {
+        const float v = (2.0f * (s[rr] * R[0][rr])) * dS[cc][0] + (2.0f * (s[rr] * R[1][rr])) * dS[cc][1] +
+                        (2.0f * (s[rr] * R[2][rr])) * dS[cc][2];
+        dMt[rr][cc] = v;
+      }
+    // Rt[c][r] = R[r][c];  dL_dscale_k = dot(Rt[k], dMt[k])
+    float ds[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) ds[k] = R[0][k] * dMt[k][0] + R[1][k] * dMt[k][1] + R[2][k] * dMt[k][2];
+    dL_dscale[3 * idx] = ds[0]; dL_dscale[3 * idx + 1] = ds[1]; dL_dscale[3 * idx + 2] = ds[2];
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++) dMt[k][rr] *= s[k];
+#define Dm(ci, ri) dMt[ci][ri]
+    const float dq0 = 2 * z * (Dm(0, 1) - Dm(1, 0)) + 2 * y * (Dm(2, 0) - Dm(0, 2)) + 2 * x * (Dm(1, 2) - Dm(2, 1));
+    const float dq1 = 2 * y * (Dm(1, 0) + Dm(0, 1)) + 2 * z * (Dm(2, 0) + Dm(0, 2)) + 2 * r * (Dm(1, 2) - Dm(2, 1)) -
+                      4 * x * (Dm(2, 2) + Dm(1, 1));
+    const float dq2 = 2 * x * (Dm(1, 0) + Dm(0, 1)) + 2 * r * (Dm(2, 0) - Dm(0, 2)) + 2 * z * (Dm(1, 2) + Dm(2, 1)) -
+                      4 * y * (Dm(2, 2) + Dm(0, 0));
+    const float dq3 = 2 * r * (Dm(0, 1) - Dm(1, 0)) + 2 * x * (Dm(2, 0) + Dm(0, 2)) + 2 * y * (Dm(1, 2) + Dm(2, 1)) -
+                      4 * z * (Dm(1, 1) + Dm(0, 0));
+#undef Dm
+    dL_drot[4 * idx] = dq0; dL_drot[4 * idx + 1] = dq1; dL_drot[4 * idx + 2] = dq2; dL_drot[4 * idx + 3] = dq3;
+  } else {
+    dL_dscale[3 * idx] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f;
+    dL_drot[4 * idx] = 0.f; dL_drot[4 * idx + 1] = 0.f; dL_drot[4 * idx + 2] = 0.f; dL_drot[4 * idx + 3] = 0.f;
+  }
+}
+
+// V1.  Replaces checkFrustum / in_frustum (reference rasterizer_impl.cu:52-60, auxiliary.h:120-144).
+__global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float* __restrict__ means3D,
+                                                            const float* __restrict__ V,
+                                                            unsigned char* __restrict__ present) {
+  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  if (idx >= P) return;
+  const float z = V[2] * means3D[3 * idx] + V[6] * means3D[3 * idx + 1] + V[10] * means3D[3 * idx + 2] + V[14];
+  present[idx] = !(z <= 0.2f);
+}
+
+// ---------------------------------- launchers ----------------------------------------------------
+hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const float* scales, const float* rotations,
+                             const float* opacities, const float* shs, const float* cov3D_precomp,
+                             const float* colors_precomp, const float* view, const float* proj, const float* campos,
+                             GeomState g, int* radii_out, hipStream_t s) {
+  const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, means3D, scales, rotations, opacities, shs,
+                     cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_scan_block_sums(GeomState g, int P, hipStream_t s) {
+  const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, g.block_sums, nb, g.total);
+  return hipGetLastError();
+}
+
+hipError_t launch_duplicate(const FrameParams& fp, GeomState g, uint64_t* keys_out, uint32_t* vals_out,
+                            hipStream_t s) {
+  const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, keys_out, vals_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningState b, const int* radii,
+                                    const float* means3D, const float* scales, const float* rotations,
+                                    const float* shs, const float* cov3D_used, const float* view, const float* proj,
+                                    const float* campos, bool colors_precomp, float* dL_dmean2D, float* dL_dconic,
+                                    float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
+                                    float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s) {
+  const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  hipLaunchKernelGGL(k_gaussian_backward, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, b.grad_inst, b.inst_flag, radii,
+                     means3D, scales, rotations, shs, cov3D_used, view, proj, campos, colors_precomp ? 1 : 0,
+                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+  return hipGetLastError();
+}
+
+hipError_t launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present,
+                               hipStream_t s) {
+  const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  hipLaunchKernelGGL(k_mark_visible, dim3(nb), dim3(PRE_BLOCK), 0, s, P, means3D, view, present);
+  return hipGetLastError();
+}
+
+}  // namespace gsr

@@ -1,0 +1,338 @@
+// render.hip -- per-tile alpha blending, forward (F8) and backward (B1), for gfx950 wave64.
+//
+// Replaces renderCUDA forward (reference forward.cu:291-407) and renderCUDA backward
+// (reference backward.cu:438-603).
+//
+// Shape of both kernels (NOT the reference's 16x16-thread / 32-lane-warp structure):
+//   * one 256-thread workgroup per 16x16 tile = 4 waves; wave w owns the 8x8 pixel QUAD
+//     (w&1, w>>1) of the tile, lane l the pixel (l&7, l>>3) inside it;
+//   * the tile's depth-sorted splat list is staged through LDS in chunks of 256: every thread
+//     gathers ONE 48-B splat record (3 x dwordx4) and tests its exact-conservative footprint box
+//     (hx, hy from the preprocess) against the four quads; four 64-bit wave ballots per loader wave
+//     form per-quad hit masks in LDS -- the in-tile compaction;
+//   * each wave then walks only the set bits of its own quad's masks (scalar bit scan, s_ff1), reading
+//     the record by LDS broadcast, so a splat that cannot touch a quad costs that wave nothing.
+//     Skipping is exact: a skipped (quad, splat) pair has alpha < 1/255 for every pixel, which the
+//     reference discards as well.
+// Forward stops per wave as soon as its 64 pixels are saturated and per tile when all four are.
+// Backward emits, for each (tile, splat) instance, ONE 9-float gradient record into the splat's
+// slot (plain 16-B stores, no atomics): DPP wave reduction over the 64 pixels of a quad, partials
+// of the (up to) four quads combined in fixed order.  k_gaussian_backward sums a Gaussian's
+// records.  The reference issues 9 global atomicAdds per (pixel, splat) instead (backward.cu:565,
+// 591-600) and is run-to-run non-deterministic; this path is bitwise reproducible.
+#include "gsr_internal.hpp"
+
+namespace gsr {
+
+constexpr int CHUNK = 256;
+
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ float dpp_get(float v) {
+  // lanes whose source is masked off / out of range read 0
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, BANK_MASK, false));
+}
+
+// Sum over the 64 lanes of a wave; the total is valid in lanes 48..63 (read it from lane 63).
+// Fixed association order => deterministic.
+__device__ __forceinline__ float wave_sum_to_hi(float v) {
+  v += dpp_get<0xB1, 0xF, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xF, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_get<0x124, 0xF, 0xF>(v);  // row_ror:4
+  v += dpp_get<0x128, 0xF, 0xF>(v);  // row_ror:8  -> every lane of a 16-lane row holds the row sum
+  v += dpp_get<0x142, 0xA, 0xF>(v);  // row_bcast:15 into rows 1 and 3
+  v += dpp_get<0x143, 0xC, 0xF>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const uint32_t t = (uint32_t)__shfl_xor((int)v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+
+// Footprint box of a splat vs the four 8x8 quads of the tile at (tx0, ty0); bit q set = may touch.
+__device__ __forceinline__ uint32_t quad_hits(float x, float y, float hx, float hy, float tx0, float ty0) {
+  const float xl = x - hx, xh = x + hx, yl = y - hy, yh = y + hy;
+  const bool cx0 = (xh >= tx0) && (xl <= tx0 + 7.0f);
+  const bool cx1 = (xh >= tx0 + 8.0f) && (xl <= tx0 + 15.0f);
+  const bool cy0 = (yh >= ty0) && (yl <= ty0 + 7.0f);
+  const bool cy1 = (yh >= ty0 + 8.0f) && (yl <= ty0 + 15.0f);
+  return (uint32_t)(cx0 && cy0) | ((uint32_t)(cx1 && cy0) << 1) | ((uint32_t)(cx0 && cy1) << 2) |
+         ((uint32_t)(cx1 && cy1) << 3);
+}
+
+// ------------------------------------------------------------------------------------------------
+// F8 forward blend.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blend_forward(const FrameParams fp, const uint2* __restrict__ ranges,
+                                                       const uint32_t* __restrict__ point_list,
+                                                       const float4* __restrict__ splats,
+                                                       const float* __restrict__ bg, float* __restrict__ final_T,
+                                                       uint32_t* __restrict__ n_contrib,
+                                                       uint32_t* __restrict__ tile_last, float* __restrict__ out_color,
+                                                       float* __restrict__ out_depth, float* __restrict__ out_acc) {
+  __shared__ float4 sA[CHUNK], sB[CHUNK], sC[CHUNK];
+  __shared__ uint64_t smask[4][4];  // [quad][loader wave]
+  __shared__ uint32_t s_last;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tile = blockIdx.y * fp.gx + blockIdx.x;
+  const int px = blockIdx.x * TILE + (w & 1) * 8 + (lane & 7);
+  const int py = blockIdx.y * TILE + (w >> 1) * 8 + (lane >> 3);
+  const bool inside = px < fp.W && py < fp.H;
+  const float pfx = (float)px, pfy = (float)py;
+  const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
+  const uint2 range = ranges[tile];
+  const int n = (int)(range.y - range.x);
+  if (tid == 0) s_last = 0;
+
+  float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, A = 0.f;
+  uint32_t last = 0;
+  bool done = !inside;
+  bool wave_done = __ballot(!done) == 0ull;
+
+  for (int base = 0; base < n; base += CHUNK) {
+    const int j = base + tid;
+    uint32_t hits = 0;
+    if (j < n) {
+      const uint32_t id = point_list[range.x + j];
+      const float4 a = splats[(size_t)id * SPLAT_F4 + 0];
+      const float4 b = splats[(size_t)id * SPLAT_F4 + 1];
+      const float4 c = splats[(size_t)id * SPLAT_F4 + 2];
+      sA[tid] = a;
+      sB[tid] = b;
+      sC[tid] = c;
+      hits = quad_hits(a.x, a.y, c.z, c.w, tx0, ty0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint64_t m = __ballot((hits >> q) & 1u);
+      if (lane == 0) smask[q][w] = m;
+    }
+    __syncthreads();
+    if (!wave_done) {
+      for (int lw = 0; lw < 4 && !wave_done; lw++) {
+        uint64_t m = uniform_u64(smask[w][lw]);
+        while (m) {
+          const int bpos = __builtin_ctzll(m);
+          m &= m - 1;
+          const int jj = lw * 64 + bpos;
+          const float4 a = sA[jj];
+          const float4 b = sB[jj];
+          const float4 c = sC[jj];
+          const float dx = a.x - pfx, dy = a.y - pfy;
+          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+          const float alpha = fminf(0.99f, b.y * __expf(power));
+          bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+          const float test_T = T * (1.0f - alpha);
+          const bool stop = ok && (test_T < 0.0001f);
+          done = done || stop;
+          ok = ok && !stop;
+          const float wgt = ok ? alpha * T : 0.0f;
+          C0 += b.z * wgt;
+          C1 += b.w * wgt;
+          C2 += c.x * wgt;
+          Dp += c.y * wgt;
+          A += wgt;
+          T = ok ? test_T : T;
+          last = ok ? (uint32_t)(base + jj + 1) : last;
+          if (__ballot(!done) == 0ull) {
+            wave_done = true;
+            break;
+          }
+        }
+      }
+    }
+    if (__syncthreads_and(wave_done)) break;
+  }
+  __syncthreads();  // s_last initialised (covers the n == 0 case, where the loop has no barrier)
+
+  const uint32_t wl = wave_max_u32(inside ? last : 0u);
+  if (lane == 0) atomicMax(&s_last, wl);
+  if (inside) {
+    const size_t pid = (size_t)fp.W * py + px;
+    const size_t N = (size_t)fp.W * fp.H;
+    final_T[pid] = T;
+    n_contrib[pid] = last;
+    out_color[pid] = C0 + T * bg[0];
+    out_color[N + pid] = C1 + T * bg[1];
+    out_color[2 * N + pid] = C2 + T * bg[2];
+    out_depth[pid] = Dp;
+    out_acc[pid] = A;
+  }
+  __syncthreads();
+  if (tid == 0) tile_last[tile] = s_last;
+}
+
+// ------------------------------------------------------------------------------------------------
+// B1 backward blend.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_blend_backward(
+    const FrameParams fp, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_last,
+    const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const uint2* __restrict__ slotinfo,
+    const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dpix, const float* __restrict__ dL_dacc, float4* __restrict__ grad_inst,
+    uint8_t* __restrict__ inst_flag) {
+  __shared__ float4 sA[CHUNK], sB[CHUNK];
+  __shared__ float sBlue[CHUNK];
+  __shared__ uint32_t sSlot[CHUNK];
+  __shared__ uint64_t smask[4][4];
+  __shared__ float sPart[4][CHUNK][9];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tile = blockIdx.y * fp.gx + blockIdx.x;
+  const int n = (int)tile_last[tile];  // entries [0, n) of the tile's list can carry gradient
+  if (n == 0) return;
+  const uint32_t rbase = ranges[tile].x;
+  const int px = blockIdx.x * TILE + (w & 1) * 8 + (lane & 7);
+  const int py = blockIdx.y * TILE + (w >> 1) * 8 + (lane >> 3);
+  const bool inside = px < fp.W && py < fp.H;
+  const float pfx = (float)px, pfy = (float)py;
+  const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
+  const size_t pid = (size_t)fp.W * py + px, N = (size_t)fp.W * fp.H;
+
+  const float T_final = inside ? final_T[pid] : 0.0f;
+  const int lastc = inside ? (int)n_contrib[pid] : 0;
+  const float dp0 = inside ? dL_dpix[pid] : 0.f, dp1 = inside ? dL_dpix[N + pid] : 0.f,
+              dp2 = inside ? dL_dpix[2 * N + pid] : 0.f;
+  const float dacc = inside ? dL_dacc[pid] : 0.f;  // the reference reads this unguarded (backward.cu:497)
+  const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+  const float ddelx_dx = 0.5f * (float)fp.W, ddely_dy = 0.5f * (float)fp.H;
+  float T = T_final;
+  float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, aacc = 0.f;  // accum_rec, accum_acc_rec
+  float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_acc = 0.f;
+
+  for (int base = 0; base < n; base += CHUNK) {
+    const int k = base + tid;  // k-th entry counted from the back of [0, n)
+    uint32_t hits = 0;
+    if (k < n) {
+      const int pos = n - 1 - k;
+      const uint32_t id = point_list[rbase + pos];
+      const float4 a = splats[(size_t)id * SPLAT_F4 + 0];
+      const float4 b = splats[(size_t)id * SPLAT_F4 + 1];
+      const float4 c = splats[(size_t)id * SPLAT_F4 + 2];
+      const uint2 si = slotinfo[id];
+      const int x0 = (int)(si.y & 1023u), y0 = (int)((si.y >> 10) & 1023u), rw = (int)(si.y >> 20);
+      sA[tid] = a;
+      sB[tid] = b;
+      sBlue[tid] = c.x;
+      sSlot[tid] = si.x + (uint32_t)(((int)blockIdx.y - y0) * rw + ((int)blockIdx.x - x0));
+      hits = quad_hits(a.x, a.y, c.z, c.w, tx0, ty0);
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const uint64_t m = __ballot((hits >> q) & 1u);
+      if (lane == 0) smask[q][w] = m;
+    }
+    __syncthreads();
+    for (int lw = 0; lw < 4; lw++) {
+      uint64_t m = uniform_u64(smask[w][lw]);
+      while (m) {
+        const int bpos = __builtin_ctzll(m);
+        m &= m - 1;
+        const int jj = lw * 64 + bpos;
+        const int pos = n - 1 - (base + jj);  // 0-based index in the tile list == `contributor` after decrement
+        const float4 a = sA[jj];
+        const float4 b = sB[jj];
+        const float blue = sBlue[jj];
+        const float dx = a.x - pfx, dy = a.y - pfy;
+        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
+        const float G = __expf(power);
+        const float alpha = fminf(0.99f, b.y * G);
+        const bool ok = (pos < lastc) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f, g7 = 0.f, g8 = 0.f;
+        if (__ballot(ok) != 0ull) {
+          const float om = 1.0f - alpha;
+          const float rom = __builtin_amdgcn_rcpf(om);
+          const float Tn = T * rom;  // T / (1 - alpha)
+          const float dch = alpha * Tn;
+          const float n0 = last_alpha * lc0 + (1.f - last_alpha) * ar0;
+          const float n1 = last_alpha * lc1 + (1.f - last_alpha) * ar1;
+          const float n2 = last_alpha * lc2 + (1.f - last_alpha) * ar2;
+          const float nacc = last_alpha * last_acc + (1.f - last_alpha) * aacc;
+          float dL_dalpha = (b.z - n0) * dp0 + (b.w - n1) * dp1 + (blue - n2) * dp2 + (1.0f - nacc) * dacc;
+          dL_dalpha *= Tn;
+          dL_dalpha += (-T_final * rom) * bg_dot;
+          const float dL_dG = b.y * dL_dalpha;
+          const float gdx = G * dx, gdy = G * dy;
+          const float dG_ddelx = -gdx * a.z - gdy * a.w;
+          const float dG_ddely = -gdy * b.x - gdx * a.w;
+          if (ok) {
+            g0 = dch * dp0;
+            g1 = dch * dp1;
+            g2 = dch * dp2;
+            g3 = dL_dG * dG_ddelx * ddelx_dx;
+            g4 = dL_dG * dG_ddely * ddely_dy;
+            g5 = -0.5f * gdx * dx * dL_dG;
+            g6 = -0.5f * gdx * dy * dL_dG;
+            g7 = -0.5f * gdy * dy * dL_dG;
+            g8 = G * dL_dalpha;
+            T = Tn;
+            ar0 = n0; ar1 = n1; ar2 = n2; aacc = nacc;
+            lc0 = b.z; lc1 = b.w; lc2 = blue; last_acc = 1.0f;
+            last_alpha = alpha;
+          }
+          g0 = wave_sum_to_hi(g0);
+          g1 = wave_sum_to_hi(g1);
+          g2 = wave_sum_to_hi(g2);
+          g3 = wave_sum_to_hi(g3);
+          g4 = wave_sum_to_hi(g4);
+          g5 = wave_sum_to_hi(g5);
+          g6 = wave_sum_to_hi(g6);
+          g7 = wave_sum_to_hi(g7);
+          g8 = wave_sum_to_hi(g8);
+        }
+        if (lane == 63) {
+          float* p = sPart[w][jj];
+          p[0] = g0; p[1] = g1; p[2] = g2; p[3] = g3; p[4] = g4; p[5] = g5; p[6] = g6; p[7] = g7; p[8] = g8;
+        }
+      }
+    }
+    __syncthreads();
+    if (k < n) {
+      // hit bits of entry `tid`, quad order 0..3 fixed => reproducible sums
+      const int lw = tid >> 6;
+      float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+      bool any = false;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        if ((smask[q][lw] >> (tid & 63)) & 1ull) {
+          any = true;
+#pragma unroll
+          for (int t = 0; t < 9; t++) s[t] += sPart[q][tid][t];
+        }
+      }
+      if (any) {
+        const size_t slot = sSlot[tid];
+        grad_inst[slot * GRAD_F4 + 0] = make_float4(s[0], s[1], s[2], s[3]);
+        grad_inst[slot * GRAD_F4 + 1] = make_float4(s[4], s[5], s[6], s[7]);
+        grad_inst[slot * GRAD_F4 + 2] = make_float4(s[8], 0.f, 0.f, 0.f);
+        inst_flag[slot] = 1;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
+                                float* out_color, float* out_depth, float* out_acc, hipStream_t s) {
+  hipLaunchKernelGGL(k_blend_forward, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, b.point_list, g.splats, bg,
+                     im.final_T, im.n_contrib, im.tile_last, out_color, out_depth, out_acc);
+  return hipGetLastError();
+}
+
+hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
+                                 const float* dL_dpix, const float* dL_dacc, hipStream_t s) {
+  hipLaunchKernelGGL(k_blend_backward, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, im.tile_last, b.point_list,
+                     g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst, b.inst_flag);
+  return hipGetLastError();
+}
+
+}  // namespace gsr

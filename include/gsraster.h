@@ -1,0 +1,133 @@
+/*
+ * gsraster.h -- C ABI of libgsraster_hip.so, the MI355X (gfx950) tile rasterizer that
+ * replaces GS-LIVM's CudaRasterizer::Rasterizer static API.
+ *
+ * Every entry point cites the reference interface it replaces (paths relative to the
+ * GS-LIVM tree).  All pointers are DEVICE pointers to f32 data unless stated; matrices
+ * are 16 floats, column-major (the layout include/gs/cuda_rasterizer/auxiliary.h:48-64
+ * indexes).  Nullable pointers follow the reference's convention: NULL == "not
+ * provided" (a size-0 tensor in the Torch binding, src/gs/rasterizer.cu:178-193).
+ *
+ * No Torch, GLM or STL types cross this boundary.  The library never allocates or frees
+ * device memory: scratch comes from the three allocator callbacks (forward) or from the
+ * blobs those callbacks returned (backward).  All work is enqueued on `stream`
+ * (a hipStream_t passed as void*; NULL = the null stream).
+ *
+ * Errors: functions return a negative gsr_status; gsr_last_error() returns a
+ * thread-local message.  (The reference throws std::runtime_error / exits; a C ABI
+ * cannot, the binding in gs-livm_amd/csrc/torch_binding.cpp converts.)
+ */
+#ifndef GSRASTER_H_INCLUDED
+#define GSRASTER_H_INCLUDED
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GSR_ABI_VERSION 1
+
+typedef enum gsr_status {
+  GSR_OK = 0,
+  GSR_ERR_INVALID_ARGUMENT = -1, /* bad shape / null required pointer                 */
+  GSR_ERR_ALLOC = -2,            /* an allocator callback returned NULL               */
+  GSR_ERR_HIP = -3,              /* a HIP runtime call or kernel launch failed        */
+  GSR_ERR_UNSUPPORTED = -4       /* e.g. SH degree > 3, M > 16                        */
+} gsr_status;
+
+/* Replaces std::function<char*(size_t)> (include/gs/cuda_rasterizer/rasterizer.h:24-26;
+ * Torch side: resizeFunctional, src/gs/rasterize_points.cu:36-44).  Called at most once
+ * per gsr_forward per blob; must return device memory (>= `bytes`, 256-B aligned) that
+ * stays valid until the matching gsr_backward has completed on the stream. */
+typedef char* (*gsr_alloc_fn)(void* ctx, size_t bytes);
+
+/* Replaces CudaRasterizer::Rasterizer::forward (rasterizer.h:23-51,
+ * src/cuda_rasterizer/rasterizer_impl.cu:181-342).
+ *   P Gaussians, D = SH degree (0..3), M = SH coefficients per Gaussian (shs is [P][M][3]).
+ *   out_color [3][H][W] planar, out_depth [H][W], out_acc [H][W] are fully written.
+ *   radii [P] int32 (nullable: an internal array is used, as rasterizer_impl.cu:217-219).
+ *   prefiltered / debug: accepted for signature parity; prefiltered has no effect in the
+ *   reference forward either; debug != 0 synchronises the
+ *   stream after every stage and reports kernel errors (auxiliary.h:146-154).
+ * Returns num_rendered (R >= 0), or a negative gsr_status.  Like the reference this
+ * call blocks the host once (R must be known to size the binning blob,
+ * rasterizer_impl.cu:277). */
+int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
+                gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
+                int height, const float* means3D, const float* shs, const float* colors_precomp,
+                const float* opacities, const float* scales, float scale_modifier, const float* rotations,
+                const float* cov3D_precomp, const float* viewmatrix, const float* projmatrix, const float* cam_pos,
+                float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_acc,
+                int* radii, int debug, void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:53-88,
+ * rasterizer_impl.cu:346-457).  geom/binning/image blobs are the ones the forward
+ * allocator callbacks returned; R is gsr_forward's return value.
+ * The nine gradient outputs are FULLY OVERWRITTEN (Gaussians with radii <= 0 get
+ * zeros), so the caller need not pre-zero them (the reference requires zeroed buffers,
+ * rasterize_points.cu:173-181; zeroed buffers remain valid input).
+ *   dL_dmean2D [P][3] (.x,.y written, .z = 0), dL_dconic [P][4] (.x,.y,.w; .z = 0),
+ *   dL_dopacity [P], dL_dcolor [P][3], dL_dmean3D [P][3], dL_dcov3D [P][6],
+ *   dL_dsh [P][M][3], dL_dscale [P][3], dL_drot [P][4].
+ * The gradient w.r.t. depth is not an input, exactly as in the reference
+ * (src/gs/rasterizer.cu:79; backward.cu:451-452). */
+int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
+                 const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
+                 const float* rotations, const float* cov3D_precomp, const float* viewmatrix,
+                 const float* projmatrix, const float* campos, float tan_fovx, float tan_fovy, const int* radii,
+                 char* geom_buffer, char* binning_buffer, char* image_buffer, const float* dL_dpix,
+                 const float* dL_dacc, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+                 float* dL_dmean3D, float* dL_dcov3D, float* dL_dsh, float* dL_dscale, float* dL_drot, int debug,
+                 void* stream);
+
+/* Replaces CudaRasterizer::Rasterizer::markVisible (rasterizer.h:21,
+ * rasterizer_impl.cu:128-135): present[i] = z_view > 0.2 (1-byte bool). */
+int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const float* projmatrix,
+                     unsigned char* present, void* stream);
+
+/* Replace required<GeometryState|ImageState|BinningState>() (rasterizer_impl.h:62-67):
+ * bytes the corresponding allocator callback will be asked for. */
+size_t gsr_geometry_bytes(int P);
+size_t gsr_image_bytes(int width, int height);
+size_t gsr_binning_bytes(int R);
+
+/* Views into the opaque blobs, for parity tests and tooling (the reference exposes the
+ * same arrays through GeometryState/BinningState/ImageState, rasterizer_impl.h:28-60).
+ * Pointers are device pointers into the blob; arrays the implementation does not keep
+ * are NULL. */
+typedef struct gsr_geometry_view {
+  const float* depths;            /* [P]                                  */
+  const int32_t* radii;           /* [P] internal radii                   */
+  const float* splats;            /* [P][12]: x, y, conic.x, conic.y, conic.z, opacity, r, g, b, depth, hx, hy */
+  const float* cov3D;             /* [P][6]                               */
+  const uint32_t* tiles_touched;  /* [P]                                  */
+  const uint32_t* point_offsets;  /* [P] inclusive scan                   */
+  const uint8_t* clamped;         /* [P] bit0..2 = r,g,b clamp flags      */
+} gsr_geometry_view;
+typedef struct gsr_binning_view {
+  const uint64_t* keys_unsorted;  /* [R] valid until gsr_backward runs    */
+  const uint32_t* values_unsorted;/* [R] valid until gsr_backward runs    */
+  const uint64_t* keys;           /* [R] sorted; valid until gsr_backward */
+  const uint32_t* point_list;     /* [R] sorted Gaussian ids              */
+} gsr_binning_view;
+typedef struct gsr_image_view {
+  const uint32_t* ranges;         /* [tiles][2]                           */
+  const float* final_T;           /* [H][W]                               */
+  const uint32_t* n_contrib;      /* [H][W]                               */
+} gsr_image_view;
+int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out);
+int gsr_binning_view_of(char* binning_buffer, int R, gsr_binning_view* out);
+int gsr_image_view_of(char* image_buffer, int width, int height, gsr_image_view* out);
+
+/* getHigherMsb (rasterizer_impl.cu:35-48): number of tile-id bits the sort covers. */
+uint32_t gsr_higher_msb(uint32_t n);
+
+const char* gsr_last_error(void);
+int gsr_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GSRASTER_H_INCLUDED */

@@ -1,0 +1,46 @@
+"""Shared helpers for the parity tests: numpy scene -> device tensors -> C ABI -> numpy."""
+import numpy as np
+import torch
+
+import gs_livm_amd as G
+
+
+def to_dev(scene, dev):
+    t = {}
+    for k in ("bg", "means3D", "shs", "opacities", "scales", "rotations", "viewmatrix", "projmatrix", "campos",
+              "colors_precomp", "cov3D_precomp"):
+        v = scene.get(k)
+        t[k] = torch.empty(0, device=dev) if v is None else torch.from_numpy(np.ascontiguousarray(v)).to(dev)
+    return t
+
+
+def hip_forward(scene, dev, debug=True):
+    t = to_dev(scene, dev)
+    out = G.rasterize_forward(t["bg"], t["means3D"], t["colors_precomp"], t["opacities"], t["scales"],
+                              t["rotations"], scene.get("scale_modifier", 1.0), t["cov3D_precomp"], t["viewmatrix"],
+                              t["projmatrix"], scene["tanfovx"], scene["tanfovy"], scene["H"], scene["W"], t["shs"],
+                              scene["sh_degree"], t["campos"], False, debug)
+    return t, out
+
+
+def hip_backward(scene, t, fwd, dL_dcolor, dL_dacc, dev, debug=True):
+    R, color, depth, acc, radii, geom, binning, img = fwd
+    dc = torch.from_numpy(dL_dcolor).to(dev)
+    da = torch.from_numpy(dL_dacc).to(dev)
+    g = G.rasterize_backward(t["bg"], t["means3D"], radii, t["colors_precomp"], t["scales"], t["rotations"],
+                             scene.get("scale_modifier", 1.0), t["cov3D_precomp"], t["viewmatrix"], t["projmatrix"],
+                             scene["tanfovx"], scene["tanfovy"], dc, da, t["shs"], scene["sh_degree"], t["campos"],
+                             geom, R, binning, img, debug, return_conic=True)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations", "dL_dconic")
+    return {n: x.cpu().numpy() for n, x in zip(names, g)}
+
+
+def grad_close(got, ref, name):
+    """SURVEY.md Appendix B tolerance: |d| <= 1e-5 * max|g| + 1e-4 * |g| (order of f32 summation differs)."""
+    ref = ref.reshape(got.shape)
+    scale = float(np.abs(ref).max()) if ref.size else 0.0
+    tol = 1e-5 * scale + 1e-4 * np.abs(ref)
+    bad = np.abs(got - ref) > tol
+    assert not bad.any(), "%s: %d / %d outside tolerance, worst |d|=%.3e (max|g|=%.3e)" % (
+        name, int(bad.sum()), bad.size, float(np.abs(got - ref).max()), scale)
