@@ -1,0 +1,74 @@
+"""View-parallel execution across the GPUs of one node.
+
+The views rendered in one optimiser iteration are independent forward/backward passes over the SAME
+Gaussian set (reference src/liw/lioOptimization.cpp:1691-1737) whose gradients are summed
+(:1822-1825).  So: one process per GPU, the parameter buffer replicated, rank r renders the views
+`shard_views(...)` assigns to it, and the only exchange steps are
+  * `reduce_gradients`   -- sum of the per-view parameter gradients onto the optimiser owner, and
+  * `broadcast_gaussians` -- the owner's updated parameter buffer back to every replica,
+both on one flat f32 buffer (56 B per Gaussian at M = 1) so each is a single large RCCL collective
+over xGMI.  The rasterizer itself never communicates.  Backend "nccl" is RCCL on ROCm; the same
+code runs on "gloo" for the CPU tests.
+"""
+from collections import OrderedDict
+
+import torch
+import torch.distributed as dist
+
+# parameter groups in buffer order: name -> trailing shape as a function of M
+_LAYOUT = OrderedDict([("means3D", lambda M: (3,)), ("scales", lambda M: (3,)), ("rotations", lambda M: (4,)),
+                       ("opacities", lambda M: (1,)), ("shs", lambda M: (M, 3))])
+
+
+def floats_per_gaussian(M):
+    return 11 + 3 * M
+
+
+class GaussianBuffer:
+    """One contiguous f32 buffer holding every per-Gaussian parameter group as SoA blocks
+    [means3D | scales | rotations | opacities | shs]; `views` are zero-copy tensors into it."""
+
+    def __init__(self, P, M, device, dtype=torch.float32):
+        self.P, self.M = int(P), int(M)
+        self.flat = torch.zeros(self.P * floats_per_gaussian(self.M), dtype=dtype, device=device)
+        self.views = OrderedDict()
+        off = 0
+        for name, shp in _LAYOUT.items():
+            shape = (self.P,) + shp(self.M)
+            n = 1
+            for d in shape:
+                n *= d
+            self.views[name] = self.flat[off:off + n].view(shape)
+            off += n
+        assert off == self.flat.numel()
+
+    def load(self, arrays):
+        for name, v in self.views.items():
+            v.copy_(torch.as_tensor(arrays[name]).reshape(v.shape))
+        return self
+
+    def nbytes(self):
+        return self.flat.numel() * self.flat.element_size()
+
+
+def shard_views(n_views, rank, world_size):
+    """Views of one iteration assigned to `rank`: round-robin, so any n_views >= 0 is covered exactly once."""
+    return list(range(rank, n_views, world_size))
+
+
+def broadcast_gaussians(buf, src=0, group=None):
+    """Owner -> replicas: one collective on the flat parameter buffer."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(buf.flat if isinstance(buf, GaussianBuffer) else buf, src=src, group=group)
+    return buf
+
+
+def reduce_gradients(grad, dst=0, group=None, all_ranks=False):
+    """Sum of per-view gradients (flat buffer of the same layout) onto the owner (or everywhere)."""
+    t = grad.flat if isinstance(grad, GaussianBuffer) else grad
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        if all_ranks:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        else:
+            dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
+    return grad

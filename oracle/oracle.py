@@ -62,6 +62,7 @@ _FIELDS = {
     "out_color": (np.float32, lambda P, R, W, H, T: (3, H, W)),
     "out_depth": (np.float32, lambda P, R, W, H, T: (1, H, W)),
     "out_acc": (np.float32, lambda P, R, W, H, T: (1, H, W)),
+    "fragile": (np.uint8, lambda P, R, W, H, T: (H, W)),
 }
 
 

@@ -1,0 +1,75 @@
+"""CPU tests of the C-ABI boundary: the library loads without a GPU, exports every symbol that
+include/gsraster.h declares, and rejects bad arguments before touching the device."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import gs_livm_amd as G
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    h = open(os.path.join(ROOT, "include", "gsraster.h")).read()
+    h = re.sub(r"/\*.*?\*/", "", h, flags=re.S)
+    return sorted(set(re.findall(r"\b(gsr_[a-z_0-9]+)\s*\(", h)) - {"gsr_alloc_fn"})
+
+
+def test_library_exports_every_declared_symbol():
+    L = G.lib()
+    names = _declared()
+    assert set(names) == set(G._capi.EXPORTS), (names, G._capi.EXPORTS)
+    for n in names:
+        assert hasattr(L, n), n
+    assert L.gsr_abi_version() == 1
+
+
+def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):
+    monkeypatch.setattr(G._capi, "_lib", None)
+    monkeypatch.setattr(G._capi, "LIB_PATH", str(tmp_path / "absent.so"))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        G._capi.lib()
+
+
+def test_size_helpers():
+    L = G.lib()
+    assert L.gsr_geometry_bytes(0) > 0 and L.gsr_binning_bytes(0) > 0
+    prev = 0
+    for P in (1, 256, 257, 10_000, 2_000_000):
+        b = L.gsr_geometry_bytes(P)
+        assert b >= prev and b % 256 == 0
+        prev = b
+    # per-instance footprint: point_list 4 B + max(sort buffers, 48-B gradient records) + 1-B flag
+    per = (L.gsr_binning_bytes(40_000_000) - L.gsr_binning_bytes(0)) / 40e6
+    assert 52.9 < per < 54.0
+    assert L.gsr_image_bytes(1920, 1080) >= 1920 * 1080 * 8 + 8160 * 12
+
+
+def test_higher_msb_equals_oracle():
+    L = G.lib()
+    for n in list(range(1, 300)) + [1200, 3600, 8160, 65535, 65536, 1 << 20]:
+        assert L.gsr_higher_msb(n) == O.higher_msb(n), n
+
+
+def test_argument_errors_are_reported_not_crashed():
+    L = G.lib()
+    noop = G._capi.ALLOC_FN(lambda ctx, n: None)
+    null = C.c_void_p(None)
+    rc = L.gsr_forward(noop, None, noop, None, noop, None, -1, 0, 1, null, 64, 64, null, null, null, null, null, 1.0,
+                       null, null, null, null, null, 1.0, 1.0, 0, null, null, null, null, 0, null)
+    assert rc == -1 and b"bad P" in L.gsr_last_error()
+    one = C.c_void_p(1)  # never dereferenced: validation fails first
+    rc = L.gsr_forward(noop, None, noop, None, noop, None, 5, 0, 1, one, 64, 64, null, null, null, one, one, 1.0,
+                       one, null, one, one, one, 1.0, 1.0, 0, one, one, one, null, 0, null)
+    assert rc == -1 and b"null required input" in L.gsr_last_error()
+    rc = L.gsr_forward(noop, None, noop, None, noop, None, 5, 4, 25, one, 64, 64, one, one, null, one, one, 1.0,
+                       one, null, one, one, one, 1.0, 1.0, 0, one, one, one, null, 0, null)
+    assert rc == -4 and b"SH degree" in L.gsr_last_error()
+    rc = L.gsr_backward(-1, 0, 1, 0, null, 64, 64, *([null] * 4), 1.0, *([null] * 5), 1.0, 1.0, *([null] * 15), 0,
+                        null)
+    assert rc == -1
+    assert L.gsr_mark_visible(-3, null, null, null, null, null) == -1
+    assert L.gsr_mark_visible(0, null, null, null, null, null) == 0

@@ -1,0 +1,131 @@
+"""CPU tests of the host-side logic: operator-surface argument rules, synthetic scene / camera
+conventions, view sharding and the two exchange steps over gloo with world_size 2."""
+import math
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import gs_livm_amd as G
+from gs_livm_amd import multiview as MV
+from gs_livm_amd import synthetic as S
+
+
+def _settings():
+    cam = S.make_camera(64, 48)
+    return G.GaussianRasterizationSettings(48, 64, cam["tanfovx"], cam["tanfovy"], torch.ones(3), 1.0,
+                                           torch.from_numpy(cam["viewmatrix"]), torch.from_numpy(cam["projmatrix"]), 0,
+                                           torch.from_numpy(cam["campos"]), False)
+
+
+def test_rasterizer_argument_exclusivity():
+    """src/gs/rasterizer.cu:161-169: exactly one of shs/colors and one of (scales,rotations)/cov3D."""
+    r = G.GaussianRasterizer(_settings())
+    m, o = torch.zeros(4, 3), torch.zeros(4, 1)
+    with pytest.raises(ValueError, match="SHs or precomputed colors"):
+        r(m, m, o, shs=None, colors_precomp=None, scales=m, rotations=torch.zeros(4, 4))
+    with pytest.raises(ValueError, match="SHs or precomputed colors"):
+        r(m, m, o, shs=torch.zeros(4, 1, 3), colors_precomp=m, scales=m, rotations=torch.zeros(4, 4))
+    with pytest.raises(ValueError, match="scale/rotation pair"):
+        r(m, m, o, shs=torch.zeros(4, 1, 3))
+    with pytest.raises(ValueError, match="scale/rotation pair"):
+        r(m, m, o, shs=torch.zeros(4, 1, 3), scales=m, rotations=torch.zeros(4, 4), cov3D_precomp=torch.zeros(4, 6))
+
+
+def test_forward_shape_error_like_reference():
+    """src/gs/rasterize_points.cu:67-69"""
+    with pytest.raises(ValueError, match=r"\(num_points, 3\)"):
+        G.rasterize_forward(torch.ones(3), torch.zeros(4, 2), None, None, None, None, 1.0, None, None, None, 1, 1, 8,
+                            8, None, 0, None)
+
+
+def test_camera_conventions():
+    cam = S.make_camera(1920, 1080, yaw_deg=15.0, position=(0.5, -0.2, 1.0))
+    V, F = cam["viewmatrix"], cam["projmatrix"]
+    assert np.allclose(V[:3, 3], 0) and V[3, 3] == 1  # transposed world->view: translation in the last ROW
+    p = np.array([0.5, -0.2, 1.0, 1.0], np.float32)
+    assert np.allclose(p @ V, [0, 0, 0, 1], atol=1e-6)  # camera centre maps to the view origin
+    assert np.allclose(cam["campos"], [0.5, -0.2, 1.0], atol=1e-6)
+    P = S.projection_matrix(S.ZNEAR, S.ZFAR, math.radians(60), math.radians(40))
+    assert P[3, 2] == 1 and np.isclose(P[2, 2], 100 / 99.99) and np.isclose(P[2, 3], -1 / 99.99)  # camera.cu:66-76
+    assert np.allclose(F, V @ S.projection_matrix(S.ZNEAR, S.ZFAR, math.radians(60), 2 * math.atan(
+        math.tan(math.radians(30)) * 1080 / 1920)).T, atol=1e-6)
+    assert np.isclose(cam["tanfovx"], math.tan(math.radians(30)))
+
+
+def test_scene_generator_is_seeded_and_exercises_culls():
+    a, b = S.make_scene(5000, 320, 240, 9, 1), S.make_scene(5000, 320, 240, 9, 1)
+    assert all(np.array_equal(a[k], b[k]) for k in ("means3D", "scales", "rotations", "opacities", "shs"))
+    assert np.allclose(np.linalg.norm(a["rotations"], axis=1), 1, atol=1e-6)
+    assert 0.005 < (a["means3D"][:, 2] <= 0.2).mean() < 0.05 and 0.002 < (a["scales"] > 0.3).any(1).mean() < 0.03
+    assert a["shs"].shape == (5000, 4, 3) and a["opacities"].min() >= 0.05
+
+
+def test_shard_views_covers_every_view_once():
+    for n in (0, 1, 3, 8, 11):
+        for w in (1, 2, 4, 8):
+            got = sorted(v for r in range(w) for v in MV.shard_views(n, r, w))
+            assert got == list(range(n))
+
+
+def test_gaussian_buffer_layout():
+    g = S.make_gaussians(100, 3, sh_degree=1)
+    buf = MV.GaussianBuffer(100, 4, "cpu").load(g)
+    assert buf.flat.numel() == 100 * MV.floats_per_gaussian(4) and buf.nbytes() == 100 * 23 * 4
+    assert MV.floats_per_gaussian(1) * 4 == 56 and MV.floats_per_gaussian(16) * 4 == 236
+    for k, v in buf.views.items():
+        assert v.data_ptr() >= buf.flat.data_ptr() and np.array_equal(v.numpy(), g[k])
+    buf.views["opacities"].fill_(0.25)
+    assert (buf.flat[100 * 10:100 * 11] == 0.25).all()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        P, M = 500, 4
+        buf = MV.GaussianBuffer(P, M, "cpu")
+        if rank == 0:
+            buf.load(S.make_gaussians(P, 17, sh_degree=1))
+        MV.broadcast_gaussians(buf, src=0)
+        want = S.make_gaussians(P, 17, sh_degree=1)
+        ok = all(np.array_equal(buf.views[k].numpy(), want[k]) for k in buf.views)
+        # each rank "renders" its views: gradient = (view index + 1) everywhere; owner gets the sum
+        mine = MV.shard_views(5, rank, world)
+        grad = MV.GaussianBuffer(P, M, "cpu")
+        for v in mine:
+            grad.flat += float(v + 1)
+        MV.reduce_gradients(grad, dst=0)
+        if rank == 0:
+            ok = ok and bool((grad.flat == 15.0).all())
+        grad2 = torch.full((7,), float(rank + 1))
+        MV.reduce_gradients(grad2, all_ranks=True)
+        ok = ok and bool((grad2 == 3.0).all())
+        q.put((rank, ok, mine))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_steps_world_size_2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p.start() for p in ps]
+    res = sorted(q.get(timeout=120) for _ in ps)
+    [p.join(60) for p in ps]
+    assert all(p.exitcode == 0 for p in ps)
+    assert res[0][1] and res[1][1]
+    assert res[0][2] == [0, 2, 4] and res[1][2] == [1, 3]

@@ -1,0 +1,177 @@
+"""CPU tests of the oracle (oracle/gsr_oracle.c): the known answer on record from the reference,
+the committed golden vectors, structural properties of the restated pipeline, and a
+finite-difference check of the restated backward against the restated forward."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from gs_livm_amd import synthetic as S
+from oracle import oracle as O
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _single(mean, scale, rot, opacity=0.8, W=640, H=480, tanx=0.5, tany=0.375):
+    fovx, fovy = 2 * math.atan(tanx), 2 * math.atan(tany)
+    view = np.eye(4, dtype=np.float32)
+    proj = S.projection_matrix(S.ZNEAR, S.ZFAR, fovx, fovy).T.copy()
+    return dict(W=W, H=H, tanfovx=tanx, tanfovy=tany, viewmatrix=view, projmatrix=(view @ proj).astype(np.float32),
+                campos=np.zeros(3, np.float32), bg=np.ones(3, np.float32), means3D=np.array([mean], np.float32),
+                scales=np.array([scale], np.float32), rotations=np.array([rot], np.float32),
+                opacities=np.array([[opacity]], np.float32), shs=np.zeros((1, 1, 3), np.float32), sh_degree=0,
+                colors_precomp=None, cov3D_precomp=None)
+
+
+def test_reference_known_answer_from_survey():
+    """The only reference-produced numbers available."""
+    ka = json.load(open(os.path.join(GOLDEN, "survey_single_gaussian.json")))
+    i, e = ka["input"], ka["expected"]
+    fr = O.forward(_single(i["mean"], i["scale"], i["rotation_rxyz"], W=i["width"], H=i["height"],
+                           tanx=i["tanfovx"], tany=i["tanfovy"]))
+    assert int(fr.radii[0]) == e["radius"]
+    assert int(fr.tiles_touched[0]) == e["tiles"] and fr.R == e["tiles"]
+    assert np.allclose(fr.means2D[0], e["xy"], atol=ka["abs_tol"]["xy"], rtol=0)
+    assert np.allclose(fr.conic_opacity[0, :3], e["conic"], atol=ka["abs_tol"]["conic"], rtol=0)
+
+
+@pytest.mark.parametrize("name", ["oracle_P300_70x50_D3", "oracle_P2000_160x96_D0"])
+def test_oracle_reproduces_golden(name):
+    z = np.load(os.path.join(GOLDEN, name + ".npz"))
+    P, W, H, seed, D, R = [int(v) for v in z["meta"]]
+    sc = S.make_scene(P, W, H, seed, sh_degree=D)
+    for k in ("means3D", "scales", "rotations", "opacities", "shs", "viewmatrix", "projmatrix", "campos"):
+        assert np.array_equal(sc[k], z["in_" + k]), "scene generator drifted: " + k
+    O.set_threads(1)
+    fr = O.forward(sc)
+    assert fr.R == R
+    for k in ("radii", "tiles_touched", "point_offsets", "clamped", "keys", "point_list", "ranges", "n_contrib"):
+        assert np.array_equal(getattr(fr, k), z["fw_" + k]), k
+    for k in ("means2D", "depths", "conic_opacity"):  # pure +,-,*,/,sqrt: exact on any IEEE host
+        vis = fr.radii > 0
+        assert np.array_equal(getattr(fr, k)[vis], z["fw_" + k][vis]), k
+    for k in ("out_color", "out_depth", "out_acc", "final_T", "rgb"):  # expf / SH: libm may differ by an ulp
+        assert np.allclose(getattr(fr, k), z["fw_" + k], atol=1e-6, rtol=1e-6), k
+    g = O.backward(fr, sc, z["dL_dcolor_in"], z["dL_dacc_in"])
+    for k, v in g.items():
+        ref = z["bw_" + k]
+        assert np.allclose(v, ref, atol=1e-6 * float(np.abs(ref).max()), rtol=1e-5), k
+
+
+def test_higher_msb_matches_survey_table():
+    # tiles 1200 / 3600 / 8160 -> bit 11 / 12 / 13
+    assert [O.higher_msb(n) for n in (1200, 3600, 8160)] == [11, 12, 13]
+    for n in list(range(1, 70)) + [255, 256, 257, 65535, 65536, 2 ** 31 - 1]:
+        b = O.higher_msb(n)
+        assert n >> b == 0 and (n >> (b - 1)) != 0, n
+
+
+@pytest.fixture(scope="module")
+def c_small():
+    sc = S.make_scene(4000, 200, 120, 21, sh_degree=2)
+    return sc, O.forward(sc)
+
+
+def test_culling_rules(c_small):
+    sc, fr = c_small
+    vz = sc["means3D"] @ sc["viewmatrix"][:3, 2] + sc["viewmatrix"][3, 2]
+    near = vz <= 0.2
+    big = (sc["scales"] > 0.3).any(1)
+    assert near.any() and big.any()
+    assert (fr.radii[near] == 0).all() and (fr.radii[big] == 0).all()  # Appendix A.1 / A.2
+    assert np.array_equal(O.mark_visible(sc["means3D"], sc["viewmatrix"]), ~near)
+    assert ((fr.radii > 0) == (fr.tiles_touched > 0)).all()
+
+
+def test_keys_sorted_stably_and_ranges_partition(c_small):
+    sc, fr = c_small
+    assert fr.R == int(fr.tiles_touched.sum()) == int(fr.point_offsets[-1])
+    k = fr.keys
+    assert (k[1:] >= k[:-1]).all()
+    tie = k[1:] == k[:-1]
+    assert (fr.point_list[1:][tie] > fr.point_list[:-1][tie]).all()  # ties keep ascending Gaussian id (A.13)
+    tiles = (k >> np.uint64(32)).astype(np.int64)
+    depth_bits = (k & np.uint64(0xFFFFFFFF)).astype(np.uint32)
+    assert np.array_equal(depth_bits, fr.depths[fr.point_list].view(np.uint32))
+    gx, gy = (sc["W"] + 15) // 16, (sc["H"] + 15) // 16
+    cnt = np.bincount(tiles, minlength=gx * gy)
+    r = fr.ranges.astype(np.int64)
+    assert np.array_equal(r[:, 1] - r[:, 0], cnt)
+    nz = cnt > 0
+    assert np.array_equal(r[nz, 0], (np.cumsum(cnt) - cnt)[nz])
+    assert (r[~nz] == 0).all()
+
+
+def test_blend_invariants(c_small):
+    sc, fr = c_small
+    # sum_i alpha_i T_i = 1 - T_final (telescoping), colour = sum + T*bg with bg = 1
+    assert np.allclose(fr.out_acc[0] + fr.final_T, 1.0, atol=2e-5)
+    assert (fr.out_acc >= 0).all() and (fr.final_T > 0).all() and (fr.final_T <= 1).all()
+    r = fr.ranges.astype(np.int64)
+    gx = (sc["W"] + 15) // 16
+    ln = (r[:, 1] - r[:, 0]).reshape(-1, gx)
+    per_pixel_len = np.repeat(np.repeat(ln, 16, 0), 16, 1)[:sc["H"], :sc["W"]]
+    assert (fr.n_contrib <= per_pixel_len).all()
+
+
+def test_empty_and_fully_culled():
+    sc = S.make_scene(50, 64, 48, 3)
+    sc["means3D"][:, 2] = -1.0  # everything behind the camera
+    fr = O.forward(sc)
+    assert fr.R == 0 and (fr.radii == 0).all() and (fr.ranges == 0).all()
+    assert np.array_equal(fr.out_color, np.ones_like(fr.out_color)) and (fr.out_acc == 0).all()
+    g = O.backward(fr, sc, *S.make_upstream_grads(64, 48, 3))
+    assert all((v == 0).all() for v in g.values())
+
+
+def _loss(sc, dcol, dacc):
+    fr = O.forward(sc, keep_handle=False)
+    return float((fr.out_color.astype(np.float64) * dcol).sum() + (fr.out_acc.astype(np.float64) * dacc).sum())
+
+
+@pytest.mark.parametrize("param,gname,eps0", [("means3D", "dL_dmeans3D", 1e-3), ("scales", "dL_dscales", 2e-4),
+                                               ("rotations", "dL_drotations", 1e-3),
+                                               ("opacities", "dL_dopacity", 2e-3), ("shs", "dL_dsh", 1e-2)])
+def test_backward_matches_finite_differences(param, gname, eps0):
+    """Central differences of L = <color, dL_dcolor> + <acc, dL_dacc> in single coordinates.
+    The forward is discontinuous (alpha < 1/255 cut, radius-derived tile membership), so each
+    derivative is estimated at four step sizes; a coordinate passes when two of them agree with the
+    analytic gradient to 1 %, and 80 % of the probed coordinates must pass.  This pins the restated backward
+    (chain rule incl. the acc path and the absent quaternion-normalisation Jacobian) to the restated
+    forward, for which no reference vector exists."""
+    rng = np.random.default_rng(5)
+    W, H = 48, 32
+    sc = S.make_scene(40, W, H, 31, sh_degree=1)
+    sc["means3D"][:, 2] = rng.uniform(2.0, 4.0, 40).astype(np.float32)
+    sc["means3D"][:, :2] *= 0.3
+    sc["scales"] = rng.uniform(0.02, 0.08, (40, 3)).astype(np.float32)
+    dcol = rng.standard_normal((3, H, W)).astype(np.float32)
+    dacc = rng.standard_normal((1, H, W)).astype(np.float32)
+    O.set_threads(1)
+    fr = O.forward(sc)
+    g = O.backward(fr, sc, dcol, dacc)[gname].astype(np.float64)
+    base = sc[param].copy()
+    g = g.reshape(base.shape)
+    vis = np.flatnonzero(fr.radii > 0)
+    assert vis.size >= 8
+    probes, good = 0, 0
+    for gi in vis[:14]:
+        for rep in range(2):
+            idx = (gi,) + tuple(rng.integers(0, n) for n in base.shape[1:])
+            an, agree = float(g[idx]), 0
+            for eps in (2 * eps0, eps0, 0.5 * eps0, 0.25 * eps0):
+                sc[param] = base.copy()
+                sc[param][idx] += np.float32(eps)
+                hi = float(sc[param][idx])
+                lp = _loss(sc, dcol, dacc)
+                sc[param] = base.copy()
+                sc[param][idx] -= np.float32(eps)
+                lo = float(sc[param][idx])
+                fd = (lp - _loss(sc, dcol, dacc)) / (hi - lo)
+                agree += abs(fd - an) <= 0.01 * max(abs(fd), abs(an)) + 2e-3
+            probes += 1
+            good += agree >= 2  # a cut crossed inside [x-eps, x+eps] spoils some step sizes, not all
+    sc[param] = base
+    assert good >= 0.8 * probes, "only %d / %d coordinates agree with finite differences" % (good, probes)
