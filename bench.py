@@ -1,0 +1,237 @@
+#!/usr/bin/env python3
+"""bench.py -- the hot path of BASELINE.json on MI355X: rasterizer forward + backward (+ the caller's
+activation / Adam step that BASELINE config C3 names) on synthetic data.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C1]
+
+One STEP = one optimiser iteration over one 1920x1080 view per GPU of the C3 scene (2 M Gaussians, seed 3,
+SH degree 0 -- the product setting): activations (sigmoid / exp / normalize, torch)
+-> GaussianRasterizer forward (HIP, through the C ABI) -> synthetic upstream gradients dL/dcolor, dL/dacc
+ -> rasterizer backward (HIP) -> activation backward -> Adam step (torch, reference learning
+rates).  Inputs are resident in HBM before the timed region.  value = Mpixels/s of the whole job.
+
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): rank r renders view r of the same scene
+(yaw offsets of SURVEY.md 8(d)); per step the optimiser owner (rank 0) broadcasts the flat parameter buffer,
+every rank renders forward + backward, the per-view gradients are reduced onto rank 0, rank 0 steps Adam
+(SURVEY.md 8(e)).  scaling = "weak".
+
+Extra objects on the JSON line: "roofline" (dominant kernel, algorithmic bytes / hipEvent-measured launch
+time vs 8 TB/s), "cpu_baseline" (the CPU oracle on the same workload, host cores, rank 0 at N = 1 only),
+"kernels" (per-kernel ms per step) and "workload_stats" (measured P_vis, R, list lengths).
+"""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import gs_livm_amd as G  # noqa: E402
+from gs_livm_amd import multiview as MV  # noqa: E402
+from gs_livm_amd import synthetic as S  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes(P, P_vis, R, W, H, M, tiles, n_pass):
+    """SURVEY.md section 8(d) per-kernel algorithmic bytes per LAUNCH (see DESIGN.md 'Measurement')."""
+    return {
+        "k_preprocess": P * (44 + 12 * M) + P * 8 + P_vis * 67,
+        "k_scan_block_sums": P * 8,
+        "k_duplicate": P * 20 + R * 12,
+        "k_sort_hist": R * 8,
+        "k_sort_scan_chunks": 0, "k_sort_scan_top": 0,
+        "k_sort_scatter": R * 24,                      # read 12 B + write 12 B per pair per pass
+        "k_tile_ranges": R * 8 + tiles * 8,
+        "k_blend_forward": R * 44 + W * H * 28,
+        "k_blend_backward": W * H * 24 + R * 40 + R * 36,
+        "k_gaussian_backward": P * (108 + 12 * M) + P_vis * (111 + 12 * M) + P_vis * (64 + 12 * M),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", default="C3", choices=sorted(S.CONFIGS))
+    ap.add_argument("--sh-degree", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-adam", action="store_true", help="time rasterizer fwd+bwd only (diagnostic)")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    n_gpus = world if world > 1 else 1
+    if args.gpus != n_gpus and rank == 0:
+        print("note: --gpus %d but WORLD_SIZE %d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
+
+    P, W, H, seed = S.CONFIGS[args.workload]
+    D = args.sh_degree
+    M = (D + 1) ** 2
+    g = S.make_gaussians(P, seed, sh_degree=D, aspect=W / H)
+    yaw = S.C4_YAWS_DEG[rank % len(S.C4_YAWS_DEG)] if n_gpus > 1 else 0.0
+    cam = S.make_camera(W, H, yaw_deg=yaw)
+
+    # ---- leaf parameters in one flat buffer (the "Gaussian buffer" of BASELINE C4), pre-activation ----
+    params = MV.GaussianBuffer(P, M, dev)
+    grads = MV.GaussianBuffer(P, M, dev)
+    pre = dict(means3D=g["means3D"], scales=np.log(g["scales"]), rotations=g["rotations"],
+               opacities=np.log(g["opacities"] / (1.0 - g["opacities"])), shs=g["shs"])
+    if rank == 0:
+        params.load({k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in pre.items()})
+    MV.broadcast_gaussians(params, src=0)
+    leaves = {k: torch.nn.Parameter(v) for k, v in params.views.items()}
+    for k, p in leaves.items():
+        p.grad = grads.views[k]  # autograd accumulates in place -> gradients live in one flat buffer too
+    # reference learning rates (config/basic_common.yaml:55-62; groups as src/gs/gaussian.cu:401-427, eps 1e-15)
+    lrs = dict(means3D=1.6e-4, shs=2.5e-3, opacities=5e-2, scales=5e-3, rotations=1e-3)
+    opt = torch.optim.Adam([{"params": [leaves[k]], "lr": lrs[k]} for k in leaves], eps=1e-15, fused=True)
+
+    bg = torch.ones(3, device=dev)
+    settings = G.GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], bg, 1.0,
+                                               torch.from_numpy(cam["viewmatrix"]).to(dev),
+                                               torch.from_numpy(cam["projmatrix"]).to(dev), D,
+                                               torch.from_numpy(cam["campos"]).to(dev), False)
+    raster = G.GaussianRasterizer(settings)
+    dcol, dacc = S.make_upstream_grads(W, H, seed + rank)
+    wc, wa = torch.from_numpy(dcol).to(dev), torch.from_numpy(dacc).to(dev)
+    means2D = torch.zeros((P, 3), device=dev, requires_grad=True)  # gradient sink, as render_utils.cuh:39-40
+
+    def activated():
+        return (leaves["means3D"], torch.sigmoid(leaves["opacities"]), torch.exp(leaves["scales"]),
+                torch.nn.functional.normalize(leaves["rotations"], dim=1), leaves["shs"])
+
+    def step():
+        if n_gpus > 1:
+            MV.broadcast_gaussians(params, src=0)
+        xyz, op, sc, rot, shs = activated()
+        color, radii, depth, acc = raster(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
+        loss = (color * wc).sum() + (acc * wa).sum()
+        grads.flat.zero_()
+        means2D.grad = None
+        loss.backward()
+        if n_gpus > 1:
+            MV.reduce_gradients(grads, dst=0)
+        if rank == 0 and not args.no_adam:
+            opt.step()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    G.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    G.profile_enable(False)
+    prof = G.profile_read()
+    if dist is not None:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+
+    # ---- workload statistics from one direct forward with the current parameters ----
+    with torch.no_grad():
+        xyz, op, sc, rot, shs = [t.contiguous() for t in activated()]
+        e = torch.empty(0, device=dev)
+        fw = G.rasterize_forward(bg, xyz, e, op, sc, rot, 1.0, e, settings.viewmatrix, settings.projmatrix,
+                                 settings.tanfovx, settings.tanfovy, H, W, shs, D, settings.camera_center)
+        R, radii = fw[0], fw[4]
+        P_vis = int((radii > 0).sum())
+        v = G.state_views(fw[5], fw[6], fw[7], P, R, W, H)
+        ln = (v["ranges"][:, 1] - v["ranges"][:, 0]).float()
+        stats = dict(P=P, P_vis=P_vis, R=R, tiles=int(ln.numel()), mean_tile_list=float(ln.mean()),
+                     max_tile_list=int(ln.max()), mean_contrib_per_pixel=float(v["n_contrib"].float().mean()))
+    tiles = stats["tiles"]
+    n_pass = (32 + int(G.lib().gsr_higher_msb(tiles)) + 7) // 8
+    alg = algorithmic_bytes(P, P_vis, R, W, H, M, tiles, n_pass)
+    kernels = {}
+    for name, (ms, cnt) in prof.items():
+        if cnt:
+            kernels[name] = dict(ms_per_step=ms / args.steps, launches_per_step=cnt / args.steps,
+                                 avg_launch_ms=ms / cnt,
+                                 alg_GBps=(alg.get(name, 0) / (ms / cnt * 1e-3) / 1e9) if ms > 0 else None)
+    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    achieved = alg[dom] / (kernels[dom]["avg_launch_ms"] * 1e-3) / 1e9
+    roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_ms=round(kernels[dom]["avg_launch_ms"], 4))
+    # whole-path figure of SURVEY.md 8(d): B_alg(fwd+bwd) / t
+    b_path = (alg["k_preprocess"] + alg["k_scan_block_sums"] + alg["k_duplicate"] + n_pass * alg["k_sort_scatter"] +
+              alg["k_tile_ranges"] + alg["k_blend_forward"] + alg["k_blend_backward"] + alg["k_gaussian_backward"])
+    raster_ms = sum(k["ms_per_step"] for k in kernels.values())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    mpix = n_gpus * W * H * args.steps / elapsed / 1e6
+    out = {
+        "metric": "rasterizer fwd+bwd Mpixels/s @%dx%d, %d Gaussians (ms_per_step = ms/frame)" % (W, H, P),
+        "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: %d Gaussians, %dx%d, SH degree %d, 1 view per GPU, fwd+bwd + Adam step" %
+                               (args.workload, P, W, H, D),
+                   "views_per_step": n_gpus, "parallelism": "view-parallel x%d" % n_gpus,
+                   "adam_in_step": not args.no_adam},
+        "fps": round(1e3 / ms_per_step * n_gpus, 2),
+        "roofline": roofline,
+        "whole_path": {"kernel_ms_per_step": round(raster_ms, 4), "algorithmic_GB_per_step": round(b_path / 1e9, 3),
+                       "alg_GBps_over_kernel_time": round(b_path / (raster_ms * 1e-3) / 1e9, 1) if raster_ms else None},
+        "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in d.items()}
+                    for k, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
+        "workload_stats": stats,
+    }
+
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(g, cam, dcol, dacc, W, H, D)
+    if rank == 0:
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(g, cam, dcol, dacc, W, H, D):
+    """The CPU oracle (oracle/gsr_oracle.c, a restatement -- kind 'port') on the same workload: one full frame
+    forward + backward on all host cores available to this process."""
+    from oracle import oracle as O
+    sc = dict(g, **cam, bg=np.ones(3, np.float32), scale_modifier=1.0, colors_precomp=None, cov3D_precomp=None)
+    threads = min(O.max_threads(), len(os.sched_getaffinity(0)))
+    O.set_threads(threads)
+    t0 = time.perf_counter()
+    fr = O.forward(sc)
+    t1 = time.perf_counter()
+    O.backward(fr, sc, dcol, dacc)
+    t2 = time.perf_counter()
+    fr.close()
+    sec = t2 - t0
+    return {"value": round(W * H / sec / 1e6, 4), "unit": "Mpixels/s", "cores": threads, "kind": "port",
+            "sample": "1 frame forward+backward of the same workload (%dx%d, %d Gaussians, R=%d); fwd %.2f s, bwd %.2f s"
+                      % (W, H, g["means3D"].shape[0], fr.R, t1 - t0, t2 - t1),
+            "ms_per_frame": round(sec * 1e3, 1)}
+
+
+if __name__ == "__main__":
+    main()

@@ -11,8 +11,8 @@ Layout (only what the hot path needs):
 The directory is named `gs-livm_amd`; import it as `gs_livm_amd` (alias module at the repo root).
 """
 from . import multiview, synthetic  # noqa: F401
-from ._capi import (GsrError, LIB_PATH, lib, mark_visible, rasterize_backward,  # noqa: F401
-                    rasterize_forward, state_views)
+from ._capi import (GsrError, LIB_PATH, lib, mark_visible, profile_enable, profile_read,  # noqa: F401
+                    rasterize_backward, rasterize_forward, state_views)
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,  # noqa: F401
                          rasterize_gaussians)
 

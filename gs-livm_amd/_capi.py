@@ -33,7 +33,8 @@ _lib = None
 
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_bytes", "gsr_image_bytes",
            "gsr_binning_bytes", "gsr_geometry_view_of", "gsr_binning_view_of", "gsr_image_view_of",
-           "gsr_higher_msb", "gsr_last_error", "gsr_abi_version")
+           "gsr_higher_msb", "gsr_last_error", "gsr_abi_version", "gsr_kernel_count", "gsr_kernel_name",
+           "gsr_profile_enable", "gsr_profile_read")
 
 
 def lib():
@@ -67,6 +68,12 @@ def lib():
     L.gsr_higher_msb.argtypes = [C.c_uint32]
     L.gsr_last_error.restype = C.c_char_p
     L.gsr_abi_version.restype = ci
+    L.gsr_kernel_count.restype = ci
+    L.gsr_kernel_name.restype = C.c_char_p
+    L.gsr_kernel_name.argtypes = [ci]
+    L.gsr_profile_enable.argtypes = [ci]
+    L.gsr_profile_read.restype = ci
+    L.gsr_profile_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(ci)]
     _lib = L
     return L
 
@@ -216,3 +223,18 @@ def state_views(geomBuffer, binningBuffer, imageBuffer, P, R, W, H):
             out.update(keys=_sub(binningBuffer, bv.keys, R, torch.int64),
                        point_list=_sub(binningBuffer, bv.point_list, R, torch.int32))
     return out
+
+
+def profile_enable(on=True):
+    """Start / stop recording a hipEvent pair around every kernel launch (bench.py's roofline line)."""
+    _check(lib().gsr_profile_enable(int(bool(on))))
+
+
+def profile_read():
+    """{kernel name: (total_ms, launches)} since the last read; synchronises the recorded events."""
+    L = lib()
+    n = L.gsr_kernel_count()
+    ms = (C.c_double * n)()
+    cnt = (C.c_int * n)()
+    _check(L.gsr_profile_read(n, ms, cnt))
+    return {L.gsr_kernel_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}

@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <vector>
 
 #include "gsr_internal.hpp"
 
@@ -35,7 +36,52 @@ static int fail(int code, const char* fmt, ...) {
     if (debug) HIP_TRY(hipStreamSynchronize(stream));                                             \
   } while (0)
 
+// ---- optional event profiler -------------------------------------------------------------------
+namespace gsr {
+bool g_prof_on = false;
+static std::vector<hipEvent_t> g_ev;  // pool: [2*i] start, [2*i+1] stop
+static std::vector<int> g_ev_id;
+static size_t g_ev_used = 0;
+void prof_begin(int id, hipStream_t s) {
+  if (g_ev_used == g_ev_id.size()) {
+    hipEvent_t a, b;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_prof_on = false; return; }
+    g_ev.push_back(a); g_ev.push_back(b); g_ev_id.push_back(id);
+  }
+  g_ev_id[g_ev_used] = id;
+  (void)hipEventRecord(g_ev[2 * g_ev_used], s);
+}
+void prof_end(hipStream_t s) {
+  if (g_ev_used < g_ev_id.size()) { (void)hipEventRecord(g_ev[2 * g_ev_used + 1], s); g_ev_used++; }
+}
+}  // namespace gsr
+static const char* const kKernelNames[K_COUNT] = {
+    "k_preprocess", "k_scan_block_sums", "k_duplicate", "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top",
+    "k_sort_scatter", "k_tile_ranges", "k_blend_forward", "k_blend_backward", "k_gaussian_backward",
+    "k_mark_visible"};
+
 extern "C" {
+
+int gsr_kernel_count(void) { return K_COUNT; }
+const char* gsr_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
+int gsr_profile_enable(int on) {
+  g_ev_used = 0;
+  g_prof_on = on != 0;
+  return GSR_OK;
+}
+int gsr_profile_read(int max_ids, double* total_ms, int* launches) {
+  const int n = max_ids < K_COUNT ? max_ids : (int)K_COUNT;
+  for (int i = 0; i < n; i++) { total_ms[i] = 0.0; launches[i] = 0; }
+  for (size_t i = 0; i < g_ev_used; i++) {
+    HIP_TRY(hipEventSynchronize(g_ev[2 * i + 1]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, g_ev[2 * i], g_ev[2 * i + 1]));
+    const int id = g_ev_id[i];
+    if (id < n) { total_ms[id] += ms; launches[id]++; }
+  }
+  g_ev_used = 0;
+  return n;
+}
 
 const char* gsr_last_error(void) { return g_err; }
 int gsr_abi_version(void) { return GSR_ABI_VERSION; }

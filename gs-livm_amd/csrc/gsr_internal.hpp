@@ -155,6 +155,21 @@ hipError_t launch_mark_visible(int P, const float* means3D, const float* view, u
 
 inline int sort_passes(int end_bit) { return (end_bit + 7) / 8; }
 
+// Kernel ids for the optional event profiler (api.hip); order = gsr_kernel_name().
+enum KernelId {
+  K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DUPLICATE, K_SORT_HIST, K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER,
+  K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_COUNT
+};
+void prof_begin(int id, hipStream_t s);
+void prof_end(hipStream_t s);
+extern bool g_prof_on;
+struct ProfScope {  // records a start/stop event pair around the launches in its scope while profiling is on
+  hipStream_t s;
+  bool on;
+  ProfScope(int id, hipStream_t st) : s(st), on(g_prof_on) { if (on) prof_begin(id, s); }
+  ~ProfScope() { if (on) prof_end(s); }
+};
+
 // getRect (reference auxiliary.h:39-46): tile rectangle [x0,x1) x [y0,y1) touched by a splat of
 // integer pixel radius `radius` centred at (px,py); float arithmetic with truncating casts, exactly
 // as the reference so the rectangle (and hence every sort key) matches bit for bit.  Only

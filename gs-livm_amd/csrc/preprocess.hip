@@ -552,6 +552,7 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,
                              GeomState g, int* radii_out, hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  ProfScope ps_k_preprocess(K_PREPROCESS, s);
   hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, means3D, scales, rotations, opacities, shs,
                      cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out);
   return hipGetLastError();
@@ -559,6 +560,7 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
 
 hipError_t launch_scan_block_sums(GeomState g, int P, hipStream_t s) {
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  ProfScope ps_k_scan_blocks(K_SCAN_BLOCKS, s);
   hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, g.block_sums, nb, g.total);
   return hipGetLastError();
 }
@@ -566,6 +568,7 @@ hipError_t launch_scan_block_sums(GeomState g, int P, hipStream_t s) {
 hipError_t launch_duplicate(const FrameParams& fp, GeomState g, uint64_t* keys_out, uint32_t* vals_out,
                             hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  ProfScope ps_k_duplicate(K_DUPLICATE, s);
   hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, keys_out, vals_out);
   return hipGetLastError();
 }
@@ -577,6 +580,7 @@ hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningS
                                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                                     float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  ProfScope ps_k_gaussian_bwd(K_GAUSSIAN_BWD, s);
   hipLaunchKernelGGL(k_gaussian_backward, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, b.grad_inst, b.inst_flag, radii,
                      means3D, scales, rotations, shs, cov3D_used, view, proj, campos, colors_precomp ? 1 : 0,
                      dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
@@ -586,6 +590,7 @@ hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningS
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present,
                                hipStream_t s) {
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
+  ProfScope ps_k_mark_visible(K_MARK_VISIBLE, s);
   hipLaunchKernelGGL(k_mark_visible, dim3(nb), dim3(PRE_BLOCK), 0, s, P, means3D, view, present);
   return hipGetLastError();
 }

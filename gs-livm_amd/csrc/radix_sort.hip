@@ -202,11 +202,23 @@ hipError_t launch_sort_pairs(BinningState b, int R, int end_bit, bool start_in_A
     uint64_t* kout = inA ? b.keysB : b.keysA;
     uint32_t* vout = inA ? b.valsB : b.point_list;
     const int shift = 8 * p;
-    hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, s, kin, R, ntiles, shift, b.counts);
-    hipLaunchKernelGGL(k_sort_scan_chunks, dim3(nchunks), dim3(256), 0, s, b.counts, ntiles, b.chunk_sums);
-    hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, b.chunk_sums, nchunks, b.digit_base);
-    hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout, R, ntiles, shift, b.counts,
-                       b.chunk_sums, b.digit_base);
+    {
+      ProfScope ps(K_SORT_HIST, s);
+      hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, s, kin, R, ntiles, shift, b.counts);
+    }
+    {
+      ProfScope ps(K_SORT_SCAN_CHUNKS, s);
+      hipLaunchKernelGGL(k_sort_scan_chunks, dim3(nchunks), dim3(256), 0, s, b.counts, ntiles, b.chunk_sums);
+    }
+    {
+      ProfScope ps(K_SORT_SCAN_TOP, s);
+      hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, b.chunk_sums, nchunks, b.digit_base);
+    }
+    {
+      ProfScope ps(K_SORT_SCATTER, s);
+      hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout, R, ntiles, shift,
+                         b.counts, b.chunk_sums, b.digit_base);
+    }
     inA = !inA;
   }
   return hipGetLastError();
@@ -215,7 +227,10 @@ hipError_t launch_sort_pairs(BinningState b, int R, int end_bit, bool start_in_A
 hipError_t launch_tile_ranges(const uint64_t* keys, int R, uint2* ranges, int tiles, hipStream_t s) {
   hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
   if (e != hipSuccess) return e;
-  if (R > 0) hipLaunchKernelGGL(k_tile_ranges, dim3((R + 255) / 256), dim3(256), 0, s, keys, R, ranges);
+  if (R > 0) {
+    ProfScope ps(K_TILE_RANGES, s);
+    hipLaunchKernelGGL(k_tile_ranges, dim3((R + 255) / 256), dim3(256), 0, s, keys, R, ranges);
+  }
   return hipGetLastError();
 }
 

@@ -323,6 +323,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
 
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, hipStream_t s) {
+  ProfScope ps_k_blend_fwd(K_BLEND_FWD, s);
   hipLaunchKernelGGL(k_blend_forward, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, b.point_list, g.splats, bg,
                      im.final_T, im.n_contrib, im.tile_last, out_color, out_depth, out_acc);
   return hipGetLastError();
@@ -330,6 +331,7 @@ hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState
 
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                  const float* dL_dpix, const float* dL_dacc, hipStream_t s) {
+  ProfScope ps_k_blend_bwd(K_BLEND_BWD, s);
   hipLaunchKernelGGL(k_blend_backward, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, im.tile_last, b.point_list,
                      g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst, b.inst_flag);
   return hipGetLastError();

@@ -124,6 +124,17 @@ int gsr_image_view_of(char* image_buffer, int width, int height, gsr_image_view*
 /* getHigherMsb (rasterizer_impl.cu:35-48): number of tile-id bits the sort covers. */
 uint32_t gsr_higher_msb(uint32_t n);
 
+/* Optional per-kernel device timing (hipEvent pairs recorded on the launch stream around every
+ * kernel launch while enabled).  Measurement aid for bench.py's roofline line; the reference has only
+ * host wall-clock timers (include/common/timer/timer.h:36-52).  Not thread-safe; off by default.
+ *   gsr_profile_enable(1) starts a fresh recording, gsr_profile_enable(0) stops it.
+ *   gsr_profile_read synchronises the recorded events, writes per-kernel total milliseconds and launch
+ *   counts for kernel ids [0, gsr_kernel_count()), clears the recording, returns the number of ids written. */
+int gsr_kernel_count(void);
+const char* gsr_kernel_name(int kernel_id);
+int gsr_profile_enable(int on);
+int gsr_profile_read(int max_ids, double* total_ms, int* launches);
+
 const char* gsr_last_error(void);
 int gsr_abi_version(void);
 

