@@ -65,7 +65,7 @@ extern "C" {
 int gsr_kernel_count(void) { return K_COUNT; }
 const char* gsr_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
 int gsr_profile_enable(int on) {
-  g_ev_used = 0;
+  if (on) g_ev_used = 0;  // a fresh recording; disabling keeps what was recorded for gsr_profile_read
   g_prof_on = on != 0;
   return GSR_OK;
 }
