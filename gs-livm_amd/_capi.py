@@ -18,11 +18,11 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 class GeometryView(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("depths", "radii", "splats", "cov3D", "tiles_touched", "point_offsets", "clamped")]
+                ("depths", "radii", "splats", "cov3D", "tiles_touched", "point_offsets", "clamped", "depth_order")]
 
 
 class BinningView(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("keys_unsorted", "values_unsorted", "keys", "point_list")]
+    _fields_ = [(n, C.c_void_p) for n in ("tile_ids", "point_list")]
 
 
 class ImageView(C.Structure):
@@ -213,15 +213,19 @@ def state_views(geomBuffer, binningBuffer, imageBuffer, P, R, W, H):
                    cov3D=_sub(geomBuffer, gv.cov3D, P * 6, torch.float32).view(P, 6),
                    tiles_touched=_sub(geomBuffer, gv.tiles_touched, P, torch.int32),
                    point_offsets=_sub(geomBuffer, gv.point_offsets, P, torch.int32),
-                   clamped=_sub(geomBuffer, gv.clamped, P, torch.uint8))
+                   clamped=_sub(geomBuffer, gv.clamped, P, torch.uint8),
+                   depth_order=_sub(geomBuffer, gv.depth_order, P, torch.int32))
         _check(L.gsr_image_view_of(_ptr(imageBuffer), W, H, C.byref(iv)))
         out.update(ranges=_sub(imageBuffer, iv.ranges, T * 2, torch.int32).view(T, 2),
                    final_T=_sub(imageBuffer, iv.final_T, W * H, torch.float32).view(H, W),
                    n_contrib=_sub(imageBuffer, iv.n_contrib, W * H, torch.int32).view(H, W))
         if R:
             _check(L.gsr_binning_view_of(_ptr(binningBuffer), R, C.byref(bv)))
-            out.update(keys=_sub(binningBuffer, bv.keys, R, torch.int64),
-                       point_list=_sub(binningBuffer, bv.point_list, R, torch.int32))
+            tile_ids = _sub(binningBuffer, bv.tile_ids, R, torch.int32)
+            point_list = _sub(binningBuffer, bv.point_list, R, torch.int32)
+            # the reference's 64-bit sorted keys, recomposed: (tile << 32) | bits(depth of the instance's Gaussian)
+            dbits = out["depths"].view(torch.int32)[point_list.long()].long() & 0xFFFFFFFF
+            out.update(tile_ids=tile_ids, point_list=point_list, keys=(tile_ids.long() << 32) | dbits)
     return out
 
 

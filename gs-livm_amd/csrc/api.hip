@@ -56,7 +56,7 @@ void prof_end(hipStream_t s) {
 }
 }  // namespace gsr
 static const char* const kKernelNames[K_COUNT] = {
-    "k_preprocess", "k_scan_block_sums", "k_duplicate", "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top",
+    "k_preprocess", "k_scan_block_sums", "k_depth_keys", "k_sorted_block_sums", "k_emit", "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top",
     "k_sort_scatter", "k_tile_ranges", "k_blend_forward", "k_blend_backward", "k_gaussian_backward",
     "k_mark_visible"};
 
@@ -166,14 +166,27 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   GeomState g = GeomState::carve(gblob, (size_t)P);
   ImageState im = ImageState::carve(iblob, width, height);
 
+  const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   STAGE(launch_preprocess(fp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
                           projmatrix, cam_pos, g, radii, stream));
-  STAGE(launch_scan_block_sums(g, P, stream));
+  STAGE(launch_scan_block_sums(g.block_sums, nb, g.total, stream));
   // R must be known on the host to size the binning blob: one blocking 4-byte read-back, exactly
-  // where the reference has its cudaMemcpy (rasterizer_impl.cu:277).
-  uint32_t R_host = 0;
-  HIP_TRY(hipMemcpyAsync(&R_host, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  // where the reference has its cudaMemcpy (rasterizer_impl.cu:277).  The per-Gaussian depth sort
+  // does not depend on R and is enqueued first, so the GPU keeps working while the host waits.
+  static thread_local uint32_t* pinned = nullptr;  // page-locked so the copy is truly asynchronous
+  if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault) != hipSuccess) {
+    pinned = nullptr;
+    (void)hipGetLastError();
+  }
+  uint32_t R_stack = 0;
+  uint32_t* R_dst = pinned ? pinned : &R_stack;
+  HIP_TRY(hipMemcpyAsync(R_dst, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  STAGE(launch_depth_keys(fp, g, g.dkeysA, g.order, stream));
+  STAGE(launch_sort_pairs(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, 32, /*start_in_A=*/true, stream));
+  STAGE(launch_sorted_block_sums(fp, g, stream));
+  STAGE(launch_scan_block_sums(g.block_sums2, nb, g.total + 1, stream));
   HIP_TRY(hipStreamSynchronize(stream));
+  const uint32_t R_host = *R_dst;
   if (R_host > 0x7fffffffu) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31 splat instances");
   const int R = (int)R_host;
 
@@ -182,11 +195,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   BinningState b = BinningState::carve(bblob, (size_t)R);
 
   const int tiles = fp.gx * fp.gy;
-  const int end_bit = 32 + (int)gsr_higher_msb((uint32_t)tiles);  // rasterizer_impl.cu:295
-  const bool start_in_A = (sort_passes(end_bit) % 2) == 0;
-  STAGE(launch_duplicate(fp, g, start_in_A ? b.keysA : b.keysB, start_in_A ? b.point_list : b.valsB, stream));
-  STAGE(launch_sort_pairs(b, R, end_bit, start_in_A, stream));
-  STAGE(launch_tile_ranges(b.keysA, R, im.ranges, tiles, stream));
+  const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
+  const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
+  STAGE(launch_emit(fp, g, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB, stream));
+  STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, R, tile_bits, start_in_A, stream));
+  STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, tiles, stream));
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
   return R;
 }
@@ -218,6 +231,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
 
   if (R > 0) {
     STAGE(hipMemsetAsync(b.inst_flag, 0, (size_t)R, stream));
+    STAGE(hipMemsetAsync(g.touched, 0, (size_t)P, stream));
     STAGE(launch_blend_backward(fp, g, b, im, background, dL_dpix, dL_dacc, stream));
   }
   STAGE(launch_gaussian_backward(fp, g, b, radii, means3D, scales, rotations, colors_precomp ? nullptr : shs,
@@ -248,15 +262,14 @@ int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out) {
   out->tiles_touched = g.tiles_touched;
   out->point_offsets = g.point_offsets;
   out->clamped = g.clamped;
+  out->depth_order = g.order;
   return GSR_OK;
 }
 
 int gsr_binning_view_of(char* binning_buffer, int R, gsr_binning_view* out) {
   if (!binning_buffer || !out || R < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad argument");
   BinningState b = BinningState::carve(binning_buffer, (size_t)R);
-  out->keys_unsorted = nullptr;  // not kept: the sort ping-pongs over the unsorted pairs
-  out->values_unsorted = nullptr;
-  out->keys = b.keysA;
+  out->tile_ids = b.tkeysA;
   out->point_list = b.point_list;
   return GSR_OK;
 }

@@ -11,8 +11,8 @@ constexpr int TILE = 16;             // tile edge in pixels (reference: config.h
 constexpr int SPLAT_F4 = 3;          // float4s per splat record (48 B)
 constexpr int GRAD_F4 = 3;           // float4s per per-instance gradient record (9 used of 12 floats)
 constexpr int PRE_BLOCK = 256;       // threads per block of the per-Gaussian kernels
-constexpr int SORT_TILE = 1024;      // keys per wave-tile of the radix sort (64 lanes x 16)
-constexpr int SORT_CHUNK = 64;       // wave-tiles per scan chunk
+constexpr int SORT_TILE = 4096;      // pairs per workgroup tile of the radix sort (4 waves x 64 lanes x 16)
+constexpr int SORT_CHUNK = 64;       // workgroup tiles per scan chunk
 constexpr size_t ALIGN = 256;
 
 inline size_t align_up(size_t v) { return (v + ALIGN - 1) & ~(ALIGN - 1); }
@@ -38,17 +38,39 @@ struct Carver {
 //   f4[0] = (x, y, conic.x, conic.y)  f4[1] = (conic.z, opacity, r, g)  f4[2] = (b, depth, hx, hy)
 // hx/hy: half-extents (pixels) of a box that contains every pixel the splat can contribute to
 // (alpha >= 1/255), used for exact-conservative culling of 8x8 pixel quads.
+// The Gaussians are also sorted by depth once (order[]), so the per-instance sort only has to order
+// by tile id (see BinningState).
+struct SortScratch {  // scratch of one radix sort over n (u32 key, u32 value) pairs
+  uint32_t* counts;      // [ntiles][256] per workgroup-tile digit counts -> exclusive in-chunk prefixes
+  uint32_t* chunk_sums;  // [nchunks][256] -> exclusive chunk bases
+  uint32_t* digit_base;  // [256] digit totals
+  static void carve(Carver& c, size_t n, SortScratch& s) {
+    const size_t ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const size_t nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
+    s.counts = c.take<uint32_t>(ntiles * 256);
+    s.chunk_sums = c.take<uint32_t>(nchunks * 256);
+    s.digit_base = c.take<uint32_t>(256);
+  }
+};
+
 struct GeomState {
   float* depths;
   int32_t* radii;
   float4* splats;
   float* cov3D;
   uint32_t* tiles_touched;
-  uint32_t* point_offsets;  // inclusive scan of tiles_touched
+  uint32_t* point_offsets;  // inclusive scan of tiles_touched in Gaussian-id order (= the reference's array)
   uint8_t* clamped;         // bit0..2
-  uint32_t* block_sums;     // per 256-Gaussian block: sum of tiles_touched, then exclusive offsets
+  uint32_t* block_sums;     // per 256-Gaussian block (id order): sum of tiles_touched -> exclusive offsets
   uint32_t* total;          // [1] num_rendered, device side
-  uint2* slotinfo;          // {first slot (exclusive offset), x0 | y0 << 10 | rect_width << 20} per visible Gaussian
+  uint2* slotinfo;          // {first slot of the Gaussian's instance run, x0 | y0 << 10 | rect_width << 20}
+  uint32_t* order;          // [P] Gaussian ids sorted by (depth bits, id); culled Gaussians last.  = dvalsA
+  uint32_t* dkeysA;         // [P] depth-sort ping-pong buffers
+  uint32_t* dkeysB;
+  uint32_t* dvalsB;
+  uint32_t* block_sums2;    // per 256-block of `order`: sum of tiles_touched -> exclusive offsets
+  uint8_t* touched;         // [P] 1 = the blend backward wrote at least one gradient record for this Gaussian
+  SortScratch dsort;
   static GeomState carve(char* blob, size_t P, size_t* bytes = nullptr) {
     Carver c(blob);
     GeomState g;
@@ -63,6 +85,13 @@ struct GeomState {
     g.block_sums = c.take<uint32_t>(nb + 1);
     g.total = c.take<uint32_t>(64);
     g.slotinfo = c.take<uint2>(P);
+    g.order = c.take<uint32_t>(P);
+    g.dkeysA = c.take<uint32_t>(P);
+    g.dkeysB = c.take<uint32_t>(P);
+    g.dvalsB = c.take<uint32_t>(P);
+    g.block_sums2 = c.take<uint32_t>(nb + 1);
+    g.touched = c.take<uint8_t>(P);
+    SortScratch::carve(c, P, g.dsort);
     if (bytes) *bytes = align_up(c.off) + ALIGN;
     return g;
   }
@@ -88,34 +117,31 @@ struct ImageState {
   }
 };
 
-// Per-instance state (replaces BinningState, rasterizer_impl.cu:161-177).  The sort ping-pongs
-// between (keysA, point_list) and (keysB, valsB); the final pass always lands in keysA/point_list.
+// Per-instance state (replaces BinningState, rasterizer_impl.cu:161-177).  Instances are EMITTED in
+// depth order (Gaussians walked through GeomState::order), each Gaussian's run contiguous, with a
+// 32-bit key = tile id.  A stable sort on the tile id alone (2 radix passes at 1080p instead of the 6
+// a (tile|depth) 64-bit key needs) then yields exactly the reference's order: by tile, then depth
+// bits, then Gaussian id.  The sort ping-pongs between (tkeysA, point_list) and (tkeysB, ivalsB); the
+// final pass always lands in tkeysA/point_list.
 // After the forward only point_list is live, so the backward's per-instance gradient records
-// (grad_inst, 48 B each, indexed by UNSORTED slot = the Gaussian's contiguous run) alias the
-// sort buffers.
+// (grad_inst, 48 B each, indexed by emission slot) alias the sort buffers.
 struct BinningState {
-  uint32_t* point_list;
-  uint64_t* keysA;
-  uint64_t* keysB;
-  uint32_t* valsB;
-  uint32_t* counts;      // [ntiles][256] per wave-tile digit counts -> exclusive in-chunk prefixes
-  uint32_t* chunk_sums;  // [nchunks][256] -> exclusive chunk bases
-  uint32_t* digit_base;  // [256]
-  float4* grad_inst;     // [R][3], aliases keysA..counts
+  uint32_t* point_list;  // [R] sorted Gaussian ids
+  uint32_t* tkeysA;      // [R] sorted tile ids (valid until the backward runs)
+  uint32_t* tkeysB;
+  uint32_t* ivalsB;
+  SortScratch tsort;
+  float4* grad_inst;     // [R][3], aliases tkeysA..tsort
   uint8_t* inst_flag;    // [R] 1 = grad_inst[slot] was written by the blend backward
   static BinningState carve(char* blob, size_t R, size_t* bytes = nullptr) {
     Carver c(blob);
     BinningState b;
-    size_t ntiles = (R + SORT_TILE - 1) / SORT_TILE;
-    size_t nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
     b.point_list = c.take<uint32_t>(R);
     size_t mark = align_up(c.off);
-    b.keysA = c.take<uint64_t>(R);
-    b.keysB = c.take<uint64_t>(R);
-    b.valsB = c.take<uint32_t>(R);
-    b.counts = c.take<uint32_t>(ntiles * 256);
-    b.chunk_sums = c.take<uint32_t>(nchunks * 256);
-    b.digit_base = c.take<uint32_t>(256);
+    b.tkeysA = c.take<uint32_t>(R);
+    b.tkeysB = c.take<uint32_t>(R);
+    b.ivalsB = c.take<uint32_t>(R);
+    SortScratch::carve(c, R, b.tsort);
     size_t sort_end = c.off;
     Carver g(blob);
     g.off = mark;
@@ -137,10 +163,15 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
                              const float* opacities, const float* shs, const float* cov3D_precomp,
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,
                              GeomState g, int* radii_out, hipStream_t s);
-hipError_t launch_scan_block_sums(GeomState g, int P, hipStream_t s);
-hipError_t launch_duplicate(const FrameParams& fp, GeomState g, uint64_t* keys_out, uint32_t* vals_out, hipStream_t s);
-hipError_t launch_sort_pairs(BinningState b, int R, int end_bit, bool start_in_A, hipStream_t s);
-hipError_t launch_tile_ranges(const uint64_t* keys, int R, uint2* ranges, int tiles, hipStream_t s);
+hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, hipStream_t s);
+hipError_t launch_depth_keys(const FrameParams& fp, GeomState g, uint32_t* keys_out, uint32_t* vals_out, hipStream_t s);
+hipError_t launch_sorted_block_sums(const FrameParams& fp, GeomState g, hipStream_t s);
+hipError_t launch_emit(const FrameParams& fp, GeomState g, uint32_t* tkeys_out, uint32_t* ivals_out, hipStream_t s);
+// Stable LSD radix sort of n (u32, u32) pairs on key bits [0, end_bit); buffers ping-pong between
+// (keysA, valsA) and (keysB, valsB), starting in A when start_in_A.
+hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
+                             int n, int end_bit, bool start_in_A, hipStream_t s);
+hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, int tiles, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, hipStream_t s);
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
@@ -154,11 +185,13 @@ hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningS
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
 
 inline int sort_passes(int end_bit) { return (end_bit + 7) / 8; }
+// digit width: the key bits are split evenly over the passes (13 tile bits -> 7 + 6, 32 depth bits -> 4 x 8)
+inline int sort_digit_bits(int end_bit) { const int p = sort_passes(end_bit); return (end_bit + p - 1) / p; }
 
 // Kernel ids for the optional event profiler (api.hip); order = gsr_kernel_name().
 enum KernelId {
-  K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DUPLICATE, K_SORT_HIST, K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER,
-  K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_COUNT
+  K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DEPTH_KEYS, K_SORTED_SUMS, K_EMIT, K_SORT_HIST, K_SORT_SCAN_CHUNKS,
+  K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);

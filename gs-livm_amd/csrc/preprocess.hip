@@ -1,7 +1,9 @@
 // preprocess.hip -- per-Gaussian stages of the MI355X rasterizer (gfx950):
 //   F1  k_preprocess        project / cull / EWA / SH->RGB, pack 48-B splat records, per-block tile sums
-//   F2  k_scan_block_sums   exclusive scan of the per-block sums (+ total = num_rendered)
-//   F4  k_duplicate         in-block scan -> point_offsets, emit (tile|depth) keys + Gaussian ids
+//   F2  k_scan_block_sums   exclusive scan of per-block sums (+ total = num_rendered); used twice
+//   F3' k_depth_keys        point_offsets (id order) + (depth bits, id) pairs for the per-Gaussian depth sort
+//   F4  k_sorted_block_sums / k_emit   walk the Gaussians in depth order, assign each its run of instance
+//                           slots and emit (tile id, Gaussian id) pairs wave-cooperatively (coalesced)
 //   B2+B3 k_gaussian_backward  sum the per-instance gradient records of each Gaussian (no atomics,
 //        fixed order) and run the EWA / projection / SH / covariance chain rule in the same pass
 //   V1  k_mark_visible
@@ -269,15 +271,14 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// F4.  Replaces duplicateWithKeys (reference rasterizer_impl.cu:64-101).  Each block re-derives its
-// Gaussians' write offsets from block_sums (exclusive) + an in-block scan, stores the inclusive
-// point_offsets, and emits key = (tile << 32) | bits(depth), value = Gaussian id, in row-major tile
-// order.  The slot of an instance (offset_exclusive + index inside the rect) is also the index of
-// its gradient record in the backward.
+// F3'.  point_offsets = inclusive scan of tiles_touched in Gaussian-id order (the reference's
+// array, rasterizer_impl.cu:270-273; block_sums already holds the exclusive block offsets), and the
+// (key, value) pairs of the per-Gaussian depth sort: key = bits(depth) for visible Gaussians
+// (depth > 0.2, so the bit pattern orders like the value), 0xFFFFFFFF for culled ones.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PRE_BLOCK) void k_duplicate(const FrameParams fp, GeomState g,
-                                                         uint64_t* __restrict__ keys_out,
-                                                         uint32_t* __restrict__ vals_out) {
+__global__ __launch_bounds__(PRE_BLOCK) void k_depth_keys(const FrameParams fp, GeomState g,
+                                                          uint32_t* __restrict__ keys_out,
+                                                          uint32_t* __restrict__ vals_out) {
   __shared__ uint32_t wtot[PRE_BLOCK / 64];
   const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
@@ -287,21 +288,85 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_duplicate(const FrameParams fp, G
   __syncthreads();
   uint32_t off = g.block_sums[blockIdx.x];
   for (int k = 0; k < w; k++) off += wtot[k];
-  off += inc;  // inclusive
-  if (idx < fp.P) g.point_offsets[idx] = off;
-  if (n == 0) return;
-  off -= n;
-  const float4 r0 = g.splats[(size_t)idx * SPLAT_F4];
-  int x0, y0, x1, y1;
-  tile_rect(r0.x, r0.y, g.radii[idx], fp.gx, fp.gy, x0, y0, x1, y1);
-  const uint64_t dbits = (uint64_t)__float_as_uint(g.depths[idx]);
-  g.slotinfo[idx] = make_uint2(off, (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20));
-  for (int y = y0; y < y1; y++)
-    for (int x = x0; x < x1; x++) {
-      keys_out[off] = ((uint64_t)(uint32_t)(y * fp.gx + x) << 32) | dbits;
-      vals_out[off] = (uint32_t)idx;
-      off++;
+  if (idx < fp.P) {
+    g.point_offsets[idx] = off + inc;
+    keys_out[idx] = n ? __float_as_uint(g.depths[idx]) : 0xFFFFFFFFu;
+    vals_out[idx] = (uint32_t)idx;
+  }
+}
+
+// Per 256-block of the depth-sorted order: sum of tiles_touched -> block_sums2 (scanned by k_scan_block_sums).
+__global__ __launch_bounds__(PRE_BLOCK) void k_sorted_block_sums(const FrameParams fp, GeomState g) {
+  __shared__ uint32_t wsum[PRE_BLOCK / 64];
+  const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  const uint32_t n = i < fp.P ? g.tiles_touched[g.order[i]] : 0u;
+  const uint32_t ws = wave_sum_u32(n);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
+  __syncthreads();
+  if (threadIdx.x == 0) g.block_sums2[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ------------------------------------------------------------------------------------------------
+// F4.  Replaces duplicateWithKeys (reference rasterizer_impl.cu:64-101).  Gaussians are visited in
+// depth order; Gaussian order[i] gets the contiguous slot run [first, first + tiles_touched) (first =
+// exclusive scan in that order) and its instances are emitted in the reference's row-major tile order
+// with key = tile id, value = Gaussian id.  The depth part of the reference's 64-bit key is implied by
+// the emission order, which the stable tile sort preserves.  A slot is also the index of the
+// instance's gradient record in the backward.
+// Emission is wave-cooperative: the 64 runs of a wave are laid end to end and lane l writes output
+// t = l, l+64, ... -- it finds the owning Gaussian by bisection over the wave's inclusive offsets
+// (LDS) and turns the run-local index into (row, col) with an exact multiply-high division, so
+// stores are fully coalesced however skewed the tile counts are.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_BLOCK) void k_emit(const FrameParams fp, GeomState g,
+                                                    uint32_t* __restrict__ tkeys_out,
+                                                    uint32_t* __restrict__ ivals_out) {
+  __shared__ uint32_t wtot[PRE_BLOCK / 64];
+  __shared__ uint32_t s_incl[PRE_BLOCK], s_id[PRE_BLOCK], s_rect[PRE_BLOCK], s_inv[PRE_BLOCK];
+  const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t id = i < fp.P ? g.order[i] : 0u;
+  const uint32_t n = i < fp.P ? g.tiles_touched[id] : 0u;
+  const uint32_t inc = wave_incl_scan_u32(n, lane);
+  if (lane == 63) wtot[w] = inc;
+  uint32_t rect = 0, inv = 0;
+  if (n) {
+    const float4 r0 = g.splats[(size_t)id * SPLAT_F4];
+    int x0, y0, x1, y1;
+    tile_rect(r0.x, r0.y, g.radii[id], fp.gx, fp.gy, x0, y0, x1, y1);
+    const uint32_t rw = (uint32_t)(x1 - x0);
+    rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | (rw << 20);
+    inv = 0xFFFFFFFFu / rw + 1u;  // ceil(2^32 / rw) for rw > 1 (wraps to 0 for rw == 1, handled below)
+  }
+  s_incl[threadIdx.x] = inc;
+  s_id[threadIdx.x] = id;
+  s_rect[threadIdx.x] = rect;
+  s_inv[threadIdx.x] = inv;
+  __syncthreads();
+  uint32_t wbase = g.block_sums2[blockIdx.x];
+  for (int k = 0; k < w; k++) wbase += wtot[k];
+  if (n) g.slotinfo[id] = make_uint2(wbase + inc - n, rect);
+  const uint32_t total = wtot[w];
+  const uint32_t* incl = s_incl + w * 64;
+  for (uint32_t t = lane; t < total; t += 64) {
+    int lo = 0, hi = 63;  // smallest l with incl[l] > t (exists because t < total = incl[63])
+#pragma unroll
+    for (int it = 0; it < 6; it++) {
+      const int mid = (lo + hi) >> 1;
+      if (incl[mid] > t) hi = mid; else lo = mid + 1;
     }
+    const int src = w * 64 + lo;
+    const uint32_t rc = s_rect[src];
+    const uint32_t rw = rc >> 20;
+    const uint32_t excl = lo ? incl[lo - 1] : 0u;
+    const uint32_t local = t - excl;
+    // local < 2^20, rw < 2^10  =>  local * (inv*rw - 2^32) < 2^32: the multiply-high quotient is exact
+    const uint32_t row = rw == 1u ? local : __umulhi(local, s_inv[src]);
+    const uint32_t col = local - row * rw;
+    const uint32_t tile = (((rc >> 10) & 1023u) + row) * (uint32_t)fp.gx + (rc & 1023u) + col;
+    tkeys_out[wbase + t] = tile;
+    ivals_out[wbase + t] = s_id[src];
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -327,9 +392,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
   const bool vis = radii[idx] > 0;
   // ---- gather-sum of the instance records ----
   float gcol0 = 0, gcol1 = 0, gcol2 = 0, gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
-  if (vis) {
+  if (vis && g.touched[idx]) {  // most Gaussians sit behind saturated pixels everywhere: no record at all
     const uint32_t n = g.tiles_touched[idx];
-    const uint32_t first = g.point_offsets[idx] - n;
+    const uint32_t first = g.slotinfo[idx].x;
     for (uint32_t k = 0; k < n; k++) {
       const size_t slot = (size_t)first + k;
       if (inst_flag[slot]) {
@@ -558,18 +623,31 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
   return hipGetLastError();
 }
 
-hipError_t launch_scan_block_sums(GeomState g, int P, hipStream_t s) {
-  const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
-  ProfScope ps_k_scan_blocks(K_SCAN_BLOCKS, s);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, g.block_sums, nb, g.total);
+hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, hipStream_t s) {
+  ProfScope ps(K_SCAN_BLOCKS, s);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, sums, nb, total);
   return hipGetLastError();
 }
 
-hipError_t launch_duplicate(const FrameParams& fp, GeomState g, uint64_t* keys_out, uint32_t* vals_out,
-                            hipStream_t s) {
+hipError_t launch_depth_keys(const FrameParams& fp, GeomState g, uint32_t* keys_out, uint32_t* vals_out,
+                             hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
-  ProfScope ps_k_duplicate(K_DUPLICATE, s);
-  hipLaunchKernelGGL(k_duplicate, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, keys_out, vals_out);
+  ProfScope ps(K_DEPTH_KEYS, s);
+  hipLaunchKernelGGL(k_depth_keys, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, keys_out, vals_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_sorted_block_sums(const FrameParams& fp, GeomState g, hipStream_t s) {
+  const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  ProfScope ps(K_SORTED_SUMS, s);
+  hipLaunchKernelGGL(k_sorted_block_sums, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit(const FrameParams& fp, GeomState g, uint32_t* tkeys_out, uint32_t* ivals_out, hipStream_t s) {
+  const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  ProfScope ps(K_EMIT, s);
+  hipLaunchKernelGGL(k_emit, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, tkeys_out, ivals_out);
   return hipGetLastError();
 }
 

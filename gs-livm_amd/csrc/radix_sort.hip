@@ -1,32 +1,37 @@
-// radix_sort.hip -- stable LSD radix sort of (u64 key, u32 value) pairs and per-tile range
+// radix_sort.hip -- stable LSD radix sort of (u32 key, u32 value) pairs and per-tile range
 // identification, hand-written for gfx950 wave64.
 //
-// Replaces cub::DeviceRadixSort::SortPairs(begin_bit 0, end_bit 32+bit) and identifyTileRanges
-// (reference rasterizer_impl.cu:298-309, :106-125).  The permutation must equal a stable sort
-// (ties keep ascending Gaussian id); every step below is order-preserving.
+// Replaces cub::DeviceRadixSort::SortPairs(begin_bit 0, end_bit 32+bit) on 64-bit (tile|depth) keys and
+// identifyTileRanges (reference rasterizer_impl.cu:298-309, :106-125).  The reference's permutation --
+// by tile, then depth bits, then ascending Gaussian id (stable sort) -- is
+// produced here by TWO stable sorts on 32-bit keys: the P Gaussians by depth bits (4 passes over P
+// pairs), then, emitted in that order, the R instances by tile id (2 passes at 1080p).  A stable sort
+// on the minor key followed by a stable sort on the major key IS the lexicographic sort, so the result
+// is bit-identical, at roughly a quarter of the HBM traffic of six passes over R 12-byte pairs.
 //
-// Work unit: a WAVE-TILE of 1024 consecutive pairs (64 lanes x 16 steps, lane = consecutive
-// element, so loads are 512-B coalesced).  Per 8-bit pass:
-//   k_sort_hist        per-wave-tile digit counts                  counts[tile][256]
+// Work unit: a workgroup tile of 4096 consecutive pairs = 4 waves x (64 lanes x 16 steps), lane =
+// consecutive element, so loads are 256-B coalesced.  Per pass (digit of <= 8 bits):
+//   k_sort_hist        per-tile digit counts                                   counts[tile][256]
 //   k_sort_scan_chunks exclusive prefix over the 64 tiles of a chunk (in place) + chunk_sums[chunk][256]
 //   k_sort_scan_top    one wave per digit: exclusive prefix over chunks (in place) + digit totals
-//   k_sort_scatter     base(d) = digit_base[d] + chunk_base[chunk][d] + counts[tile][d]; ranks inside a
-//                      step come from a wave-wide digit match (8 ballots) + popcount of lower lanes;
-//                      per-wave running offsets live in LDS; waves are independent (no block barrier
-//                      in the main loop, no atomics, no inter-workgroup communication).
+//   k_sort_scatter     ranks inside a 64-element step come from a wave-wide digit match (<= 8 ballots) +
+//                      popcount of lower lanes, per-wave running counts live in LDS; the tile is then
+//                      REORDERED IN LDS by digit and written out run by run, so global stores are
+//                      coalesced runs instead of 64 scattered dwords per instruction.
+// Every step is order-preserving (stable); no atomics, no inter-workgroup communication.
 #include "gsr_internal.hpp"
 
 namespace gsr {
 
-constexpr int STEPS = SORT_TILE / 64;  // 16
+constexpr int WAVE_TILE = SORT_TILE / 4;  // 1024
+constexpr int STEPS = WAVE_TILE / 64;     // 16
 
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
-// 64-bit mask of the valid lanes holding the same 8-bit digit as this lane.
-__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid) {
+// 64-bit mask of the valid lanes holding the same digit (nbits wide) as this lane.
+__device__ __forceinline__ uint64_t match_digit(uint32_t d, bool valid, int nbits) {
   uint64_t m = __ballot(valid);
-#pragma unroll
-  for (int b = 0; b < 8; b++) {
+  for (int b = 0; b < nbits; b++) {
     const bool bit = (d >> b) & 1u;
     const uint64_t bm = __ballot(bit);
     m &= bit ? bm : ~bm;
@@ -43,37 +48,43 @@ __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, int lane) {
   return v;
 }
 
-__global__ __launch_bounds__(256) void k_sort_hist(const uint64_t* __restrict__ keys, int n, int ntiles, int shift,
+// Exclusive scan of one value per thread across the 256 threads of the workgroup.
+__device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, int lane, int w, uint32_t* wtot /*[4]*/) {
+  const uint32_t inc = wave_incl_scan(v, lane);
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();
+  uint32_t o = 0;
+  for (int k = 0; k < w; k++) o += wtot[k];
+  __syncthreads();
+  return o + inc - v;
+}
+
+__global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ keys, int n, int shift, int nbits,
                                                    uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[4][256];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int tile = blockIdx.x * 4 + w;
+  const uint32_t mask = (1u << nbits) - 1u;
 #pragma unroll
   for (int k = 0; k < 4; k++) hist[w][lane + 64 * k] = 0;
-  __syncthreads();
-  if (tile < ntiles) {
-    const size_t base = (size_t)tile * SORT_TILE;
-    uint64_t key[STEPS];
+  const size_t base = (size_t)blockIdx.x * SORT_TILE + (size_t)w * WAVE_TILE;
+  uint32_t key[STEPS];
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) {
-      const size_t i = base + (size_t)s * 64 + lane;
-      key[s] = i < (size_t)n ? keys[i] : 0ull;
-    }
+  for (int s = 0; s < STEPS; s++) {
+    const size_t i = base + (size_t)s * 64 + lane;
+    key[s] = i < (size_t)n ? keys[i] : 0u;
+  }
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) {
-      const size_t i = base + (size_t)s * 64 + lane;
-      const bool valid = i < (size_t)n;
-      const uint32_t d = (uint32_t)(key[s] >> shift) & 0xFFu;
-      const uint64_t m = match_digit(d, valid);
-      const int rank = __popcll(m & lanemask_lt(lane));
-      if (valid && rank == 0) hist[w][d] += (uint32_t)__popcll(m);  // one leader per digit: no conflicts
-    }
+  for (int s = 0; s < STEPS; s++) {
+    const size_t i = base + (size_t)s * 64 + lane;
+    const bool valid = i < (size_t)n;
+    const uint32_t d = (key[s] >> shift) & mask;
+    const uint64_t m = match_digit(d, valid, nbits);
+    const int rank = __popcll(m & lanemask_lt(lane));
+    if (valid && rank == 0) hist[w][d] += (uint32_t)__popcll(m);  // one leader per digit: no conflicts
   }
   __syncthreads();
-  if (tile < ntiles) {
-#pragma unroll
-    for (int k = 0; k < 4; k++) counts[(size_t)tile * 256 + lane + 64 * k] = hist[w][lane + 64 * k];
-  }
+  const int d = threadIdx.x;
+  counts[(size_t)blockIdx.x * 256 + d] = hist[0][d] + hist[1][d] + hist[2][d] + hist[3][d];
 }
 
 // grid = nchunks, block = 256 (thread = digit).
@@ -110,75 +121,98 @@ __global__ __launch_bounds__(256) void k_sort_scan_top(uint32_t* __restrict__ ch
   if (lane == 0) digit_total[d] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_sort_scatter(const uint64_t* __restrict__ keys_in,
+__global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* __restrict__ keys_in,
                                                       const uint32_t* __restrict__ vals_in,
-                                                      uint64_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                      int n, int ntiles, int shift, const uint32_t* __restrict__ counts,
+                                                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                      int n, int shift, int nbits, const uint32_t* __restrict__ counts,
                                                       const uint32_t* __restrict__ chunk_base,
                                                       const uint32_t* __restrict__ digit_total) {
-  __shared__ uint32_t woff[4][256];
-  __shared__ uint32_t dbase[256];
+  __shared__ uint32_t wcnt[4][256];  // per-wave digit counts, then per-wave local write bases
+  __shared__ uint32_t gdelta[256];   // global position of local slot p holding digit d = gdelta[d] + p
   __shared__ uint32_t wtot[4];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const int tile = blockIdx.x * 4 + w;
-  // exclusive scan of the 256 digit totals (every block recomputes it: 1 KB, L2-resident)
-  {
-    const uint32_t t = digit_total[threadIdx.x];
-    const uint32_t inc = wave_incl_scan(t, lane);
-    if (lane == 63) wtot[w] = inc;
-    __syncthreads();
-    uint32_t o = 0;
-    for (int k = 0; k < w; k++) o += wtot[k];
-    dbase[threadIdx.x] = o + inc - t;
-    __syncthreads();
-  }
-  if (tile >= ntiles) return;  // no barrier below: waves are independent from here on
-  const int chunk = tile / SORT_CHUNK;
+  __shared__ uint32_t lkey[SORT_TILE], lval[SORT_TILE];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tile = blockIdx.x;
+  const uint32_t mask = (1u << nbits) - 1u;
+  // global exclusive base of every digit (every workgroup recomputes it: 1 KB, L2-resident)
+  const uint32_t dbase = block_excl_scan_256(digit_total[tid], lane, w, wtot);
 #pragma unroll
-  for (int k = 0; k < 4; k++) {
-    const int d = lane + 64 * k;
-    woff[w][d] = dbase[d] + chunk_base[(size_t)chunk * 256 + d] + counts[(size_t)tile * 256 + d];
-  }
-  const size_t base = (size_t)tile * SORT_TILE;
-  uint64_t key[STEPS];
-  uint32_t val[STEPS];
+  for (int k = 0; k < 4; k++) wcnt[w][lane + 64 * k] = 0;
+  const size_t base = (size_t)tile * SORT_TILE + (size_t)w * WAVE_TILE;
+  uint32_t key[STEPS], val[STEPS], lrank[STEPS];
 #pragma unroll
   for (int s = 0; s < STEPS; s++) {
     const size_t i = base + (size_t)s * 64 + lane;
     const bool valid = i < (size_t)n;
-    key[s] = valid ? keys_in[i] : 0ull;
+    key[s] = valid ? keys_in[i] : 0u;
     val[s] = valid ? vals_in[i] : 0u;
   }
-  volatile uint32_t* my = woff[w];
+  // pass A: rank of every element among the equal-digit elements of ITS WAVE that precede it
+  volatile uint32_t* my = wcnt[w];
 #pragma unroll
   for (int s = 0; s < STEPS; s++) {
     const size_t i = base + (size_t)s * 64 + lane;
     const bool valid = i < (size_t)n;
-    const uint32_t d = (uint32_t)(key[s] >> shift) & 0xFFu;
-    const uint64_t m = match_digit(d, valid);
+    const uint32_t d = (key[s] >> shift) & mask;
+    const uint64_t m = match_digit(d, valid, nbits);
     const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt(lane));
-    const uint32_t off = my[d];  // same address inside a digit group: LDS broadcast
-    // LDS operations of one wave execute in issue order, so every lane has read `off` before the
-    // group leader publishes the advanced offset for the next step.
-    if (valid && rank == 0) my[d] = off + (uint32_t)__popcll(m);
-    if (valid) {
-      keys_out[off + rank] = key[s];
-      vals_out[off + rank] = val[s];
+    const uint32_t prior = my[d];  // same address inside a digit group: LDS broadcast
+    // LDS operations of one wave execute in issue order: every lane has read `prior` before the group
+    // leader publishes the advanced count for the next step.
+    if (valid && rank == 0) my[d] = prior + (uint32_t)__popcll(m);
+    lrank[s] = prior + rank;
+  }
+  __syncthreads();
+  // per digit (thread = digit): tile-local base (exclusive over digits), per-wave bases, global delta
+  {
+    const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
+    const uint32_t lbase = block_excl_scan_256(c0 + c1 + c2 + c3, lane, w, wtot);
+    wcnt[0][tid] = lbase;
+    wcnt[1][tid] = lbase + c0;
+    wcnt[2][tid] = lbase + c0 + c1;
+    wcnt[3][tid] = lbase + c0 + c1 + c2;
+    const int chunk = tile / SORT_CHUNK;
+    gdelta[tid] = dbase + chunk_base[(size_t)chunk * 256 + tid] + counts[(size_t)tile * 256 + tid] - lbase;
+  }
+  __syncthreads();
+  // pass B: stable local reorder by digit
+#pragma unroll
+  for (int s = 0; s < STEPS; s++) {
+    const size_t i = base + (size_t)s * 64 + lane;
+    if (i < (size_t)n) {
+      const uint32_t d = (key[s] >> shift) & mask;
+      const uint32_t p = wcnt[w][d] + lrank[s];
+      lkey[p] = key[s];
+      lval[p] = val[s];
+    }
+  }
+  __syncthreads();
+  // write-out: consecutive local slots of one digit are consecutive in the output
+  const size_t tile_base = (size_t)tile * SORT_TILE;
+  const uint32_t nvalid = (size_t)n - tile_base < (size_t)SORT_TILE ? (uint32_t)((size_t)n - tile_base) : SORT_TILE;
+#pragma unroll
+  for (int k = 0; k < SORT_TILE / 256; k++) {
+    const uint32_t p = (uint32_t)(k * 256 + tid);
+    if (p < nvalid) {
+      const uint32_t kk = lkey[p];
+      const uint32_t g = gdelta[(kk >> shift) & mask] + p;
+      keys_out[g] = kk;
+      vals_out[g] = lval[p];
     }
   }
 }
 
 // Replaces identifyTileRanges (reference rasterizer_impl.cu:106-125); ranges must be zeroed first
 // (the reference's cudaMemset at :311).
-__global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t* __restrict__ keys, int L,
+__global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict__ keys, int L,
                                                      uint2* __restrict__ ranges) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= L) return;
-  const uint32_t cur = (uint32_t)(keys[idx] >> 32);
+  const uint32_t cur = keys[idx];
   if (idx == 0) {
     ranges[cur].x = 0;
   } else {
-    const uint32_t prev = (uint32_t)(keys[idx - 1] >> 32);
+    const uint32_t prev = keys[idx - 1];
     if (cur != prev) {
       ranges[prev].y = (uint32_t)idx;
       ranges[cur].x = (uint32_t)idx;
@@ -187,44 +221,45 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint64_t* __restrict_
   if (idx == L - 1) ranges[cur].y = (uint32_t)L;
 }
 
-// The pairs start in (keysA, point_list) when start_in_A, else in (keysB, valsB); passes alternate
-// and the caller picks start_in_A = (passes even) so the result always lands in (keysA, point_list).
-hipError_t launch_sort_pairs(BinningState b, int R, int end_bit, bool start_in_A, hipStream_t s) {
-  if (R <= 0) return hipSuccess;
-  const int ntiles = (R + SORT_TILE - 1) / SORT_TILE;
+// The pairs start in (keysA, valsA) when start_in_A, else in (keysB, valsB); passes alternate.  The caller
+// picks start_in_A = (passes even) so the result always lands in (keysA, valsA).
+hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
+                             int n, int end_bit, bool start_in_A, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int ntiles = (n + SORT_TILE - 1) / SORT_TILE;
   const int nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
-  const int nblk = (ntiles + 3) / 4;
   const int passes = sort_passes(end_bit);
+  const int nbits = sort_digit_bits(end_bit);
   bool inA = start_in_A;
   for (int p = 0; p < passes; p++) {
-    const uint64_t* kin = inA ? b.keysA : b.keysB;
-    const uint32_t* vin = inA ? b.point_list : b.valsB;
-    uint64_t* kout = inA ? b.keysB : b.keysA;
-    uint32_t* vout = inA ? b.valsB : b.point_list;
-    const int shift = 8 * p;
+    const uint32_t* kin = inA ? keysA : keysB;
+    const uint32_t* vin = inA ? valsA : valsB;
+    uint32_t* kout = inA ? keysB : keysA;
+    uint32_t* vout = inA ? valsB : valsA;
+    const int shift = nbits * p;
     {
       ProfScope ps(K_SORT_HIST, s);
-      hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, s, kin, R, ntiles, shift, b.counts);
+      hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(256), 0, s, kin, n, shift, nbits, sc.counts);
     }
     {
       ProfScope ps(K_SORT_SCAN_CHUNKS, s);
-      hipLaunchKernelGGL(k_sort_scan_chunks, dim3(nchunks), dim3(256), 0, s, b.counts, ntiles, b.chunk_sums);
+      hipLaunchKernelGGL(k_sort_scan_chunks, dim3(nchunks), dim3(256), 0, s, sc.counts, ntiles, sc.chunk_sums);
     }
     {
       ProfScope ps(K_SORT_SCAN_TOP, s);
-      hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, b.chunk_sums, nchunks, b.digit_base);
+      hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, sc.chunk_sums, nchunks, sc.digit_base);
     }
     {
       ProfScope ps(K_SORT_SCATTER, s);
-      hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, s, kin, vin, kout, vout, R, ntiles, shift,
-                         b.counts, b.chunk_sums, b.digit_base);
+      hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits,
+                         sc.counts, sc.chunk_sums, sc.digit_base);
     }
     inA = !inA;
   }
   return hipGetLastError();
 }
 
-hipError_t launch_tile_ranges(const uint64_t* keys, int R, uint2* ranges, int tiles, hipStream_t s) {
+hipError_t launch_tile_ranges(const uint32_t* keys, int R, uint2* ranges, int tiles, hipStream_t s) {
   hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
   if (e != hipSuccess) return e;
   if (R > 0) {

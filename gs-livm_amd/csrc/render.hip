@@ -180,10 +180,10 @@ __global__ __launch_bounds__(256) void k_blend_backward(
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const uint2* __restrict__ slotinfo,
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dacc, float4* __restrict__ grad_inst,
-    uint8_t* __restrict__ inst_flag) {
+    uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched) {
   __shared__ float4 sA[CHUNK], sB[CHUNK];
   __shared__ float sBlue[CHUNK];
-  __shared__ uint32_t sSlot[CHUNK];
+  __shared__ uint32_t sSlot[CHUNK], sId[CHUNK];
   __shared__ uint64_t smask[4][4];
   __shared__ float sPart[4][CHUNK][9];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -223,6 +223,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       sA[tid] = a;
       sB[tid] = b;
       sBlue[tid] = c.x;
+      sId[tid] = id;
       sSlot[tid] = si.x + (uint32_t)(((int)blockIdx.y - y0) * rw + ((int)blockIdx.x - x0));
       hits = quad_hits(a.x, a.y, c.z, c.w, tx0, ty0);
     }
@@ -315,6 +316,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         grad_inst[slot * GRAD_F4 + 1] = make_float4(s[4], s[5], s[6], s[7]);
         grad_inst[slot * GRAD_F4 + 2] = make_float4(s[8], 0.f, 0.f, 0.f);
         inst_flag[slot] = 1;
+        touched[sId[tid]] = 1;  // same value from every writer: a benign race
       }
     }
     __syncthreads();
@@ -333,7 +335,8 @@ hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningStat
                                  const float* dL_dpix, const float* dL_dacc, hipStream_t s) {
   ProfScope ps_k_blend_bwd(K_BLEND_BWD, s);
   hipLaunchKernelGGL(k_blend_backward, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, im.tile_last, b.point_list,
-                     g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst, b.inst_flag);
+                     g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst, b.inst_flag,
+                     g.touched);
   return hipGetLastError();
 }
 

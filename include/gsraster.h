@@ -105,11 +105,13 @@ typedef struct gsr_geometry_view {
   const uint32_t* tiles_touched;  /* [P]                                  */
   const uint32_t* point_offsets;  /* [P] inclusive scan                   */
   const uint8_t* clamped;         /* [P] bit0..2 = r,g,b clamp flags      */
+  const uint32_t* depth_order;    /* [P] Gaussian ids by (depth bits, id); culled Gaussians last */
 } gsr_geometry_view;
+/* The reference's 64-bit sorted key of instance i is ((uint64)tile_ids[i] << 32) | bits(depths[point_list[i]]);
+ * this implementation sorts Gaussians by depth once and instances by tile id only, so it stores the two
+ * halves separately (same order, see gs-livm_amd/csrc/radix_sort.hip). */
 typedef struct gsr_binning_view {
-  const uint64_t* keys_unsorted;  /* [R] valid until gsr_backward runs    */
-  const uint32_t* values_unsorted;/* [R] valid until gsr_backward runs    */
-  const uint64_t* keys;           /* [R] sorted; valid until gsr_backward */
+  const uint32_t* tile_ids;       /* [R] sorted tile id per instance; valid until gsr_backward runs */
   const uint32_t* point_list;     /* [R] sorted Gaussian ids              */
 } gsr_binning_view;
 typedef struct gsr_image_view {
