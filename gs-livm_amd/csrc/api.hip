@@ -56,9 +56,9 @@ void prof_end(hipStream_t s) {
 }
 }  // namespace gsr
 static const char* const kKernelNames[K_COUNT] = {
-    "k_preprocess", "k_scan_block_sums", "k_depth_keys", "k_sorted_block_sums", "k_emit", "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top",
-    "k_sort_scatter", "k_tile_ranges", "k_blend_forward", "k_blend_backward", "k_gaussian_backward",
-    "k_mark_visible"};
+    "k_preprocess", "k_scan_block_sums", "k_depth_keys", "k_sorted_block_sums", "k_sorted_offsets", "k_emit",
+    "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top", "k_sort_scatter", "k_tile_ranges", "k_blend_forward",
+    "k_blend_backward", "k_compact_touched", "k_gather_records", "k_gaussian_backward", "k_mark_visible"};
 
 extern "C" {
 
@@ -185,6 +185,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   STAGE(launch_sort_pairs(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, 32, /*start_in_A=*/true, stream));
   STAGE(launch_sorted_block_sums(fp, g, stream));
   STAGE(launch_scan_block_sums(g.block_sums2, nb, g.total + 1, stream));
+  STAGE(launch_sorted_offsets(fp, g, stream));
   HIP_TRY(hipStreamSynchronize(stream));
   const uint32_t R_host = *R_dst;
   if (R_host > 0x7fffffffu) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31 splat instances");
@@ -197,7 +198,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const int tiles = fp.gx * fp.gy;
   const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
   const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
-  STAGE(launch_emit(fp, g, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB, stream));
+  STAGE(launch_emit(fp, g, R, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB, stream));
   STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, R, tile_bits, start_in_A, stream));
   STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, tiles, stream));
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
@@ -232,7 +233,9 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
   if (R > 0) {
     STAGE(hipMemsetAsync(b.inst_flag, 0, (size_t)R, stream));
     STAGE(hipMemsetAsync(g.touched, 0, (size_t)P, stream));
+    STAGE(hipMemsetAsync(g.total + 2, 0, sizeof(uint32_t), stream));
     STAGE(launch_blend_backward(fp, g, b, im, background, dL_dpix, dL_dacc, stream));
+    STAGE(launch_gather_records(fp, g, b, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, stream));
   }
   STAGE(launch_gaussian_backward(fp, g, b, radii, means3D, scales, rotations, colors_precomp ? nullptr : shs,
                                  cov3D_used, viewmatrix, projmatrix, campos, colors_precomp != nullptr, dL_dmean2D,

@@ -12,6 +12,7 @@ constexpr int SPLAT_F4 = 3;          // float4s per splat record (48 B)
 constexpr int GRAD_F4 = 3;           // float4s per per-instance gradient record (9 used of 12 floats)
 constexpr int PRE_BLOCK = 256;       // threads per block of the per-Gaussian kernels
 constexpr int SORT_TILE = 4096;      // pairs per workgroup tile of the radix sort (4 waves x 64 lanes x 16)
+constexpr int EMIT_CHUNK = 2048;     // instance slots emitted per workgroup
 constexpr int SORT_CHUNK = 64;       // workgroup tiles per scan chunk
 constexpr size_t ALIGN = 256;
 
@@ -69,7 +70,11 @@ struct GeomState {
   uint32_t* dkeysB;
   uint32_t* dvalsB;
   uint32_t* block_sums2;    // per 256-block of `order`: sum of tiles_touched -> exclusive offsets
+  uint32_t* soff;           // [P+1] first instance slot of order[i] (exclusive scan in depth order); soff[P] = R
+  uint32_t* srect;          // [P] packed tile rect of order[i]: x0 | y0 << 10 | width << 20
+  uint32_t* sinv;           // [P] ceil(2^32 / width) of order[i] (exact division by multiply-high)
   uint8_t* touched;         // [P] 1 = the blend backward wrote at least one gradient record for this Gaussian
+  uint32_t* tlist;          // [P] compacted ids of touched Gaussians (backward); count in total[2]
   SortScratch dsort;
   static GeomState carve(char* blob, size_t P, size_t* bytes = nullptr) {
     Carver c(blob);
@@ -90,7 +95,11 @@ struct GeomState {
     g.dkeysB = c.take<uint32_t>(P);
     g.dvalsB = c.take<uint32_t>(P);
     g.block_sums2 = c.take<uint32_t>(nb + 1);
+    g.soff = c.take<uint32_t>(P + 1);
+    g.srect = c.take<uint32_t>(P);
+    g.sinv = c.take<uint32_t>(P);
     g.touched = c.take<uint8_t>(P);
+    g.tlist = c.take<uint32_t>(P);
     SortScratch::carve(c, P, g.dsort);
     if (bytes) *bytes = align_up(c.off) + ALIGN;
     return g;
@@ -166,7 +175,11 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
 hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, hipStream_t s);
 hipError_t launch_depth_keys(const FrameParams& fp, GeomState g, uint32_t* keys_out, uint32_t* vals_out, hipStream_t s);
 hipError_t launch_sorted_block_sums(const FrameParams& fp, GeomState g, hipStream_t s);
-hipError_t launch_emit(const FrameParams& fp, GeomState g, uint32_t* tkeys_out, uint32_t* ivals_out, hipStream_t s);
+hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
+hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* tkeys_out, uint32_t* ivals_out,
+                       hipStream_t s);
+hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningState b, float* dL_dmean2D,
+                                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, hipStream_t s);
 // Stable LSD radix sort of n (u32, u32) pairs on key bits [0, end_bit); buffers ping-pong between
 // (keysA, valsA) and (keysB, valsB), starting in A when start_in_A.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
@@ -190,8 +203,9 @@ inline int sort_digit_bits(int end_bit) { const int p = sort_passes(end_bit); re
 
 // Kernel ids for the optional event profiler (api.hip); order = gsr_kernel_name().
 enum KernelId {
-  K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DEPTH_KEYS, K_SORTED_SUMS, K_EMIT, K_SORT_HIST, K_SORT_SCAN_CHUNKS,
-  K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_COUNT
+  K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DEPTH_KEYS, K_SORTED_SUMS, K_SORTED_OFFSETS, K_EMIT, K_SORT_HIST,
+  K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_COMPACT_TOUCHED,
+  K_GATHER_RECORDS, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);

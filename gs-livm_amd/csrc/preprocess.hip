@@ -308,27 +308,31 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sorted_block_sums(const FramePara
 
 // ------------------------------------------------------------------------------------------------
 // F4.  Replaces duplicateWithKeys (reference rasterizer_impl.cu:64-101).  Gaussians are visited in
-// depth order; Gaussian order[i] gets the contiguous slot run [first, first + tiles_touched) (first =
-// exclusive scan in that order) and its instances are emitted in the reference's row-major tile order
-// with key = tile id, value = Gaussian id.  The depth part of the reference's 64-bit key is implied by
-// the emission order, which the stable tile sort preserves.  A slot is also the index of the
-// instance's gradient record in the backward.
-// Emission is wave-cooperative: the 64 runs of a wave are laid end to end and lane l writes output
-// t = l, l+64, ... -- it finds the owning Gaussian by bisection over the wave's inclusive offsets
-// (LDS) and turns the run-local index into (row, col) with an exact multiply-high division, so
-// stores are fully coalesced however skewed the tile counts are.
+// depth order; Gaussian order[i] gets the contiguous slot run [soff[i], soff[i+1]) and its instances
+// are emitted in the reference's row-major tile order with key = tile id, value = Gaussian id.  The
+// depth part of the reference's 64-bit key is implied by the emission order, which the stable tile
+// sort preserves.  A slot is also the index of the instance's gradient record in the backward.
+//
+// k_sorted_offsets: exclusive scan in depth order -> soff, packed rect + reciprocal per Gaussian.
+// k_emit is OUTPUT-centric: every workgroup owns EMIT_CHUNK consecutive slots, finds the Gaussians
+// covering them with a 64-ary wave search over soff, stages their descriptors in LDS and each thread
+// turns its slots into (tile, id) by bisection + an exact multiply-high division.  Work per
+// workgroup is constant however skewed the tile counts are (the nearest Gaussians own >1000 tiles
+// each and sit next to each other in depth order), and all stores are coalesced.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PRE_BLOCK) void k_emit(const FrameParams fp, GeomState g,
-                                                    uint32_t* __restrict__ tkeys_out,
-                                                    uint32_t* __restrict__ ivals_out) {
+__global__ __launch_bounds__(PRE_BLOCK) void k_sorted_offsets(const FrameParams fp, GeomState g) {
   __shared__ uint32_t wtot[PRE_BLOCK / 64];
-  __shared__ uint32_t s_incl[PRE_BLOCK], s_id[PRE_BLOCK], s_rect[PRE_BLOCK], s_inv[PRE_BLOCK];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t id = i < fp.P ? g.order[i] : 0u;
   const uint32_t n = i < fp.P ? g.tiles_touched[id] : 0u;
   const uint32_t inc = wave_incl_scan_u32(n, lane);
   if (lane == 63) wtot[w] = inc;
+  __syncthreads();
+  uint32_t off = g.block_sums2[blockIdx.x];
+  for (int k = 0; k < w; k++) off += wtot[k];
+  off += inc - n;  // exclusive
+  if (i >= fp.P) return;
   uint32_t rect = 0, inv = 0;
   if (n) {
     const float4 r0 = g.splats[(size_t)id * SPLAT_F4];
@@ -336,36 +340,170 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_emit(const FrameParams fp, GeomSt
     tile_rect(r0.x, r0.y, g.radii[id], fp.gx, fp.gy, x0, y0, x1, y1);
     const uint32_t rw = (uint32_t)(x1 - x0);
     rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | (rw << 20);
-    inv = 0xFFFFFFFFu / rw + 1u;  // ceil(2^32 / rw) for rw > 1 (wraps to 0 for rw == 1, handled below)
+    inv = 0xFFFFFFFFu / rw + 1u;  // ceil(2^32 / rw) for rw > 1 (wraps to 0 for rw == 1, handled in k_emit)
+    g.slotinfo[id] = make_uint2(off, rect);
   }
-  s_incl[threadIdx.x] = inc;
-  s_id[threadIdx.x] = id;
-  s_rect[threadIdx.x] = rect;
-  s_inv[threadIdx.x] = inv;
+  g.soff[i] = off;
+  g.srect[i] = rect;
+  g.sinv[i] = inv;
+  if (i == fp.P - 1) g.soff[fp.P] = off + n;
+}
+
+// Number of elements of the sorted array a[0..n) that are <= key (inclusive) or < key; whole wave cooperates.
+__device__ __forceinline__ int wave_count_below(const uint32_t* __restrict__ a, int n, uint32_t key, bool inclusive,
+                                                int lane) {
+  int lo = 0, hi = n;  // a[0..lo) satisfy the predicate, a[hi..n) do not
+  while (hi - lo > 64) {
+    const int step = (hi - lo + 63) / 64;
+    const int idx = lo + lane * step;
+    const bool in = idx < hi;
+    const uint32_t v = in ? a[idx] : 0xFFFFFFFFu;
+    const bool sat = in && (inclusive ? v <= key : v < key);
+    const int cnt = __popcll(__ballot(sat));  // probes are sorted: the satisfying ones are a prefix
+    if (cnt == 0) { hi = lo; break; }
+    const int nlo = lo + (cnt - 1) * step;  // a[nlo] satisfies
+    const int nhi = nlo + step < hi ? nlo + step : hi;
+    lo = nlo + 1;
+    hi = nhi;
+  }
+  const int idx = lo + lane;
+  const bool sat = idx < hi && (inclusive ? a[idx] <= key : a[idx] < key);
+  return lo + __popcll(__ballot(sat));
+}
+
+__global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g, const int R,
+                                              uint32_t* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out) {
+  __shared__ uint32_t s_off[EMIT_CHUNK + 2], s_id[EMIT_CHUNK + 1], s_rect[EMIT_CHUNK + 1], s_inv[EMIT_CHUNK + 1];
+  __shared__ int s_range[2];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t c0 = (uint32_t)blockIdx.x * EMIT_CHUNK;
+  const uint32_t c1 = c0 + EMIT_CHUNK < (uint32_t)R ? c0 + EMIT_CHUNK : (uint32_t)R;
+  if (w == 0) {
+    // i0 = last Gaussian whose run starts at or before c0; i1 = last Gaussian whose run starts before c1
+    const int i0 = wave_count_below(g.soff, fp.P + 1, c0, true, lane) - 1;
+    const int i1 = wave_count_below(g.soff, fp.P + 1, c1, false, lane) - 1;
+    if (lane == 0) { s_range[0] = i0; s_range[1] = i1; }
+  }
   __syncthreads();
-  uint32_t wbase = g.block_sums2[blockIdx.x];
-  for (int k = 0; k < w; k++) wbase += wtot[k];
-  if (n) g.slotinfo[id] = make_uint2(wbase + inc - n, rect);
-  const uint32_t total = wtot[w];
-  const uint32_t* incl = s_incl + w * 64;
-  for (uint32_t t = lane; t < total; t += 64) {
-    int lo = 0, hi = 63;  // smallest l with incl[l] > t (exists because t < total = incl[63])
-#pragma unroll
-    for (int it = 0; it < 6; it++) {
-      const int mid = (lo + hi) >> 1;
-      if (incl[mid] > t) hi = mid; else lo = mid + 1;
+  const int i0 = s_range[0];
+  const int S = s_range[1] - i0 + 1;  // <= EMIT_CHUNK + 1: every visible Gaussian owns >= 1 slot
+  for (int j = tid; j < S; j += 256) {
+    s_off[j] = g.soff[i0 + j];
+    s_id[j] = g.order[i0 + j];
+    s_rect[j] = g.srect[i0 + j];
+    s_inv[j] = g.sinv[i0 + j];
+  }
+  __syncthreads();
+  for (uint32_t t = c0 + tid; t < c1; t += 256) {
+    int lo = 0, hi = S - 1;  // largest j with s_off[j] <= t
+    while (lo < hi) {
+      const int mid = (lo + hi + 1) >> 1;
+      if (s_off[mid] <= t) lo = mid; else hi = mid - 1;
     }
-    const int src = w * 64 + lo;
-    const uint32_t rc = s_rect[src];
+    const uint32_t rc = s_rect[lo];
     const uint32_t rw = rc >> 20;
-    const uint32_t excl = lo ? incl[lo - 1] : 0u;
-    const uint32_t local = t - excl;
+    const uint32_t local = t - s_off[lo];
     // local < 2^20, rw < 2^10  =>  local * (inv*rw - 2^32) < 2^32: the multiply-high quotient is exact
-    const uint32_t row = rw == 1u ? local : __umulhi(local, s_inv[src]);
+    const uint32_t row = rw == 1u ? local : __umulhi(local, s_inv[lo]);
     const uint32_t col = local - row * rw;
-    const uint32_t tile = (((rc >> 10) & 1023u) + row) * (uint32_t)fp.gx + (rc & 1023u) + col;
-    tkeys_out[wbase + t] = tile;
-    ivals_out[wbase + t] = s_id[src];
+    tkeys_out[t] = (((rc >> 10) & 1023u) + row) * (uint32_t)fp.gx + (rc & 1023u) + col;
+    ivals_out[t] = s_id[lo];
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward gather.  The blend backward left one 9-float record per (tile, Gaussian) instance it
+// touched, in the Gaussian's slot run, and flagged the Gaussian.  k_compact_touched lists the flagged
+// Gaussians; k_gather_records gives each ONE WAVE: lanes stride over the run's flag bytes (coalesced),
+// load the flagged records, and a fixed-tree wave reduction yields the nine sums -- every Gaussian is
+// an independent unit of work (some near ones own >1000 records, most own none), and the result is
+// bitwise reproducible because each sum has a fixed association order.  Replaces the 9 atomicAdds per
+// (pixel, Gaussian) of the reference (backward.cu:565, 591-600).
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(PRE_BLOCK) void k_compact_touched(const int P, const uint8_t* __restrict__ touched,
+                                                               uint32_t* __restrict__ list,
+                                                               uint32_t* __restrict__ count) {
+  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool t = idx < P && touched[idx];
+  const uint64_t m = __ballot(t);
+  if (m == 0ull) return;
+  uint32_t base = 0;
+  if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+  base = __shfl(base, 0, 64);
+  if (t) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+}
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_get_(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false));
+}
+__device__ __forceinline__ float row_allsum_(float v) {
+  v += dpp_get_<0xB1, 0xF>(v);
+  v += dpp_get_<0x4E, 0xF>(v);
+  v += dpp_get_<0x124, 0xF>(v);
+  v += dpp_get_<0x128, 0xF>(v);
+  return v;
+}
+__device__ __forceinline__ void swap_add32_(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap_add16_(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+__global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
+    GeomState g, const float4* __restrict__ grad_inst, const uint8_t* __restrict__ inst_flag,
+    float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
+    float* __restrict__ dL_dcolor) {
+  const int lane = threadIdx.x & 63;
+  const uint32_t nwaves = gridDim.x * (PRE_BLOCK / 64);
+  const uint32_t wid = blockIdx.x * (PRE_BLOCK / 64) + (threadIdx.x >> 6);
+  const uint32_t count = g.total[2];
+  for (uint32_t q = wid; q < count; q += nwaves) {
+    const uint32_t id = g.tlist[q];
+    const size_t first = g.slotinfo[id].x;
+    const uint32_t n = g.tiles_touched[id];
+    float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0;
+    for (uint32_t base = 0; base < n; base += 256) {
+      uint8_t f[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const uint32_t k = base + 64 * j + lane;
+        f[j] = k < n ? inst_flag[first + k] : (uint8_t)0;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (f[j]) {
+          const size_t slot = first + base + 64 * j + lane;
+          const float4 a = grad_inst[slot * GRAD_F4 + 0];
+          const float4 b = grad_inst[slot * GRAD_F4 + 1];
+          const float4 c = grad_inst[slot * GRAD_F4 + 2];
+          v0 += a.x; v1 += a.y; v2 += a.z; v3 += a.w;
+          v4 += b.x; v5 += b.y; v6 += b.z; v7 += b.w;
+          v8 += c.x;
+        }
+      }
+    }
+    // wave reduction: (v0,v4) (v1,v5) (v2,v6) (v3,v7) across half-waves, then rows, then inside rows
+    swap_add32_(v0, v4);
+    swap_add32_(v1, v5);
+    swap_add32_(v2, v6);
+    swap_add32_(v3, v7);
+    swap_add16_(v0, v2);  // rows hold v0, v2, v4, v6
+    swap_add16_(v1, v3);  // rows hold v1, v3, v5, v7
+    const float w0 = row_allsum_(v0), w1 = row_allsum_(v1);
+    v8 = row_allsum_(v8);
+    v8 += dpp_get_<0x142, 0xA>(v8);  // row_bcast:15
+    v8 += dpp_get_<0x143, 0xC>(v8);  // row_bcast:31 -> total in lane 63
+    // record layout: (col r,g,b, mean2D.x | mean2D.y, conic.x, conic.y, conic.w | opacity)
+    if (lane == 0) { dL_dcolor[3 * id] = w0; dL_dcolor[3 * id + 1] = w1; }
+    if (lane == 16) { dL_dcolor[3 * id + 2] = w0; dL_dmean2D[3 * id] = w1; }
+    if (lane == 32) { dL_dmean2D[3 * id + 1] = w0; dL_dconic[4 * id] = w1; }
+    if (lane == 48) { dL_dconic[4 * id + 1] = w0; dL_dconic[4 * id + 3] = w1; }
+    if (lane == 63) dL_dopacity[id] = v8;
   }
 }
 
@@ -379,12 +517,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_emit(const FrameParams fp, GeomSt
 // Every output element of Gaussian idx is written (zeros when radii <= 0).
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
-    const FrameParams fp, GeomState g, const float4* __restrict__ grad_inst, const uint8_t* __restrict__ inst_flag,
-    const int* __restrict__ radii, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const FrameParams fp, GeomState g, const int* __restrict__ radii, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ cov3D_used,
     const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos,
-    const int colors_are_precomp, float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
-    float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor, float* __restrict__ dL_dmean3D,
+    const int colors_are_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+    float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
     float* __restrict__ dL_drot) {
   const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
@@ -392,20 +529,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
   const bool vis = radii[idx] > 0;
   // ---- gather-sum of the instance records ----
   float gcol0 = 0, gcol1 = 0, gcol2 = 0, gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
-  if (vis && g.touched[idx]) {  // most Gaussians sit behind saturated pixels everywhere: no record at all
-    const uint32_t n = g.tiles_touched[idx];
-    const uint32_t first = g.slotinfo[idx].x;
-    for (uint32_t k = 0; k < n; k++) {
-      const size_t slot = (size_t)first + k;
-      if (inst_flag[slot]) {
-        const float4 a = grad_inst[slot * GRAD_F4 + 0];
-        const float4 b = grad_inst[slot * GRAD_F4 + 1];
-        const float4 c = grad_inst[slot * GRAD_F4 + 2];
-        gcol0 += a.x; gcol1 += a.y; gcol2 += a.z; gmx += a.w;
-        gmy += b.x; gca += b.y; gcb += b.z; gcc += b.w;
-        gop += c.x;
-      }
-    }
+  if (vis && g.touched[idx]) {  // sums left by k_gather_records; everything else has no record at all
+    gcol0 = dL_dcolor[3 * idx]; gcol1 = dL_dcolor[3 * idx + 1]; gcol2 = dL_dcolor[3 * idx + 2];
+    gmx = dL_dmean2D[3 * idx]; gmy = dL_dmean2D[3 * idx + 1];
+    gca = dL_dconic[4 * idx]; gcb = dL_dconic[4 * idx + 1]; gcc = dL_dconic[4 * idx + 3];
+    gop = dL_dopacity[idx];
   }
   dL_dmean2D[3 * idx] = gmx; dL_dmean2D[3 * idx + 1] = gmy; dL_dmean2D[3 * idx + 2] = 0.f;
   dL_dconic[4 * idx] = gca; dL_dconic[4 * idx + 1] = gcb; dL_dconic[4 * idx + 2] = 0.f; dL_dconic[4 * idx + 3] = gcc;
@@ -644,10 +772,34 @@ hipError_t launch_sorted_block_sums(const FrameParams& fp, GeomState g, hipStrea
   return hipGetLastError();
 }
 
-hipError_t launch_emit(const FrameParams& fp, GeomState g, uint32_t* tkeys_out, uint32_t* ivals_out, hipStream_t s) {
+hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  ProfScope ps(K_SORTED_OFFSETS, s);
+  hipLaunchKernelGGL(k_sorted_offsets, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* tkeys_out, uint32_t* ivals_out,
+                       hipStream_t s) {
+  if (R <= 0) return hipSuccess;
   ProfScope ps(K_EMIT, s);
-  hipLaunchKernelGGL(k_emit, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, tkeys_out, ivals_out);
+  hipLaunchKernelGGL(k_emit, dim3((R + EMIT_CHUNK - 1) / EMIT_CHUNK), dim3(256), 0, s, fp, g, R, tkeys_out, ivals_out);
+  return hipGetLastError();
+}
+
+hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningState b, float* dL_dmean2D,
+                                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, hipStream_t s) {
+  const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  {
+    ProfScope ps(K_COMPACT_TOUCHED, s);
+    hipLaunchKernelGGL(k_compact_touched, dim3(nb), dim3(PRE_BLOCK), 0, s, fp.P, g.touched, g.tlist, g.total + 2);
+  }
+  {
+    ProfScope ps(K_GATHER_RECORDS, s);
+    const int grid = nb < 4096 ? nb : 4096;  // grid-stride over the touched list, one Gaussian per wave
+    hipLaunchKernelGGL(k_gather_records, dim3(grid), dim3(PRE_BLOCK), 0, s, g, b.grad_inst, b.inst_flag, dL_dmean2D,
+                       dL_dconic, dL_dopacity, dL_dcolor);
+  }
   return hipGetLastError();
 }
 
@@ -659,7 +811,7 @@ hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningS
                                     float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps_k_gaussian_bwd(K_GAUSSIAN_BWD, s);
-  hipLaunchKernelGGL(k_gaussian_backward, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, b.grad_inst, b.inst_flag, radii,
+  hipLaunchKernelGGL(k_gaussian_backward, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, radii,
                      means3D, scales, rotations, shs, cov3D_used, view, proj, campos, colors_precomp ? 1 : 0,
                      dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
   return hipGetLastError();

@@ -44,6 +44,38 @@ __device__ __forceinline__ float wave_sum_to_hi(float v) {
   return v;
 }
 
+// Sums of EIGHT per-lane values over the 64 lanes of a wave in 20 cross-lane ops instead of 48:
+// v_permlane32_swap / v_permlane16_swap (gfx950) exchange half-waves / odd-even 16-lane rows between two
+// registers, so one swap + one add halves the lane span of TWO values at once; four DPP steps finish
+// the 16-lane rows.  On return w0 holds (in every lane of rows 0,1,2,3) the totals of v0,v2,v4,v6 and
+// w1 those of v1,v3,v5,v7.  Fixed association order => deterministic.
+__device__ __forceinline__ void swap_add32(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // lanes 0-31: a[l]+a[l+32]; lanes 32-63: b[l-32]+b[l]
+}
+__device__ __forceinline__ void swap_add16(float& a, float& b) {
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // rows 0,2: a's row pairs; rows 1,3: b's row pairs
+}
+__device__ __forceinline__ float row_allsum(float v) {
+  v += dpp_get<0xB1, 0xF, 0xF>(v);   // quad_perm [1,0,3,2]
+  v += dpp_get<0x4E, 0xF, 0xF>(v);   // quad_perm [2,3,0,1]
+  v += dpp_get<0x124, 0xF, 0xF>(v);  // row_ror:4
+  v += dpp_get<0x128, 0xF, 0xF>(v);  // row_ror:8
+  return v;
+}
+__device__ __forceinline__ void wave_sum8(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
+                                          float v7, float& w0, float& w1) {
+  swap_add32(v0, v4);  // v0: lo = v0 partials, hi = v4 partials
+  swap_add32(v1, v5);
+  swap_add32(v2, v6);
+  swap_add32(v3, v7);
+  swap_add16(v0, v2);  // v0 rows: v0, v2, v4, v6
+  swap_add16(v1, v3);  // v1 rows: v1, v3, v5, v7
+  w0 = row_allsum(v0);
+  w1 = row_allsum(v1);
+}
+
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -185,7 +217,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   __shared__ float sBlue[CHUNK];
   __shared__ uint32_t sSlot[CHUNK], sId[CHUNK];
   __shared__ uint64_t smask[4][4];
-  __shared__ float sPart[4][CHUNK][9];
+  __shared__ __attribute__((aligned(8))) float sPart[4][CHUNK][10];  // 9 used; 8-B aligned pairs
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tile = blockIdx.y * fp.gx + blockIdx.x;
   const int n = (int)tile_last[tile];  // entries [0, n) of the tile's list can carry gradient
@@ -261,7 +293,8 @@ __global__ __launch_bounds__(256) void k_blend_backward(
           float dL_dalpha = (b.z - n0) * dp0 + (b.w - n1) * dp1 + (blue - n2) * dp2 + (1.0f - nacc) * dacc;
           dL_dalpha *= Tn;
           dL_dalpha += (-T_final * rom) * bg_dot;
-          const float dL_dG = b.y * dL_dalpha;
+          // Factors common to every pixel of the splat (opacity, -0.5, 0.5*W, 0.5*H) are applied once per
+          // instance when the four quads are combined, not per pixel.
           const float gdx = G * dx, gdy = G * dy;
           const float dG_ddelx = -gdx * a.z - gdy * a.w;
           const float dG_ddely = -gdy * b.x - gdx * a.w;
@@ -269,30 +302,30 @@ __global__ __launch_bounds__(256) void k_blend_backward(
             g0 = dch * dp0;
             g1 = dch * dp1;
             g2 = dch * dp2;
-            g3 = dL_dG * dG_ddelx * ddelx_dx;
-            g4 = dL_dG * dG_ddely * ddely_dy;
-            g5 = -0.5f * gdx * dx * dL_dG;
-            g6 = -0.5f * gdx * dy * dL_dG;
-            g7 = -0.5f * gdy * dy * dL_dG;
+            g3 = dL_dalpha * dG_ddelx;
+            g4 = dL_dalpha * dG_ddely;
+            const float sx = dL_dalpha * gdx, sy = dL_dalpha * gdy;
+            g5 = sx * dx;
+            g6 = sx * dy;
+            g7 = sy * dy;
             g8 = G * dL_dalpha;
             T = Tn;
             ar0 = n0; ar1 = n1; ar2 = n2; aacc = nacc;
             lc0 = b.z; lc1 = b.w; lc2 = blue; last_acc = 1.0f;
             last_alpha = alpha;
           }
-          g0 = wave_sum_to_hi(g0);
-          g1 = wave_sum_to_hi(g1);
-          g2 = wave_sum_to_hi(g2);
-          g3 = wave_sum_to_hi(g3);
-          g4 = wave_sum_to_hi(g4);
-          g5 = wave_sum_to_hi(g5);
-          g6 = wave_sum_to_hi(g6);
-          g7 = wave_sum_to_hi(g7);
+          float w0, w1;
+          wave_sum8(g0, g1, g2, g3, g4, g5, g6, g7, w0, w1);
           g8 = wave_sum_to_hi(g8);
-        }
-        if (lane == 63) {
-          float* p = sPart[w][jj];
-          p[0] = g0; p[1] = g1; p[2] = g2; p[3] = g3; p[4] = g4; p[5] = g5; p[6] = g6; p[7] = g7; p[8] = g8;
+          if ((lane & 15) == 0) {  // lanes 0,16,32,48 hold the totals of (g0,g1),(g2,g3),(g4,g5),(g6,g7)
+            float2* p2 = reinterpret_cast<float2*>(sPart[w][jj]);
+            p2[lane >> 4] = make_float2(w0, w1);
+          }
+          if (lane == 63) sPart[w][jj][8] = g8;
+        } else if ((lane & 15) == 0) {
+          float2* p2 = reinterpret_cast<float2*>(sPart[w][jj]);
+          p2[lane >> 4] = make_float2(0.f, 0.f);
+          if (lane == 48) sPart[w][jj][8] = 0.f;
         }
       }
     }
@@ -312,8 +345,10 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       }
       if (any) {
         const size_t slot = sSlot[tid];
-        grad_inst[slot * GRAD_F4 + 0] = make_float4(s[0], s[1], s[2], s[3]);
-        grad_inst[slot * GRAD_F4 + 1] = make_float4(s[4], s[5], s[6], s[7]);
+        const float op = sB[tid].y;  // dL/dG = opacity * dL/dalpha; conic terms carry -0.5 (backward.cu:583-597)
+        const float mx = op * ddelx_dx, my = op * ddely_dy, mc = -0.5f * op;
+        grad_inst[slot * GRAD_F4 + 0] = make_float4(s[0], s[1], s[2], s[3] * mx);
+        grad_inst[slot * GRAD_F4 + 1] = make_float4(s[4] * my, s[5] * mc, s[6] * mc, s[7] * mc);
         grad_inst[slot * GRAD_F4 + 2] = make_float4(s[8], 0.f, 0.f, 0.f);
         inst_flag[slot] = 1;
         touched[sId[tid]] = 1;  // same value from every writer: a benign race
