@@ -16,5 +16,23 @@ from ._capi import (GsrError, LIB_PATH, lib, mark_visible, profile_enable, profi
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,  # noqa: F401
                          rasterize_gaussians)
 
+
+
+def torch_ops():
+    """The C++/LibTorch operator surface (csrc/torch_binding.cpp), built in-tree as _gsraster_torch.so.
+    This is the code GS-LIVM itself would link; raises when it has not been built (no fallback)."""
+    import importlib.util
+    import os
+    import torch  # noqa: F401  (libtorch must be loaded first)
+    lib()  # libgsraster_hip.so must resolve before the extension that links it
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_gsraster_torch.so")
+    if not os.path.exists(path):
+        raise RuntimeError("_gsraster_torch.so not built: run `python gs-livm_amd/build.py`")
+    spec = importlib.util.spec_from_file_location("_gsraster_torch", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
 __all__ = ["GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_forward",
-           "rasterize_backward", "mark_visible", "state_views", "lib", "synthetic", "multiview", "GsrError", "LIB_PATH"]
+           "rasterize_backward", "mark_visible", "state_views", "lib", "torch_ops", "synthetic", "multiview", "GsrError", "LIB_PATH"]

@@ -78,7 +78,7 @@ def build_torch_binding(force=False, verbose=False):
     for p in ce.include_paths() + [sysconfig.get_paths()["include"], os.path.join(ROOT, "include"),
                                    "/opt/rocm/include"]:
         inc += ["-I" + p]
-    cmd = (["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-sign-compare",
+    cmd = (["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-sign-compare", "-Wno-attributes",
             "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_gsraster_torch",
             "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)] + inc +
            [src, "-o", out, "-L" + tlib, "-L" + HERE, "-lgsraster_hip", "-lc10", "-lc10_hip", "-ltorch_cpu",

@@ -183,7 +183,7 @@ hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningStat
 // Stable LSD radix sort of n (u32, u32) pairs on key bits [0, end_bit); buffers ping-pong between
 // (keysA, valsA) and (keysB, valsB), starting in A when start_in_A.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
-                             int n, int end_bit, bool start_in_A, hipStream_t s);
+                             int n, int end_bit, bool start_in_A, bool is_depth_sort, hipStream_t s);
 hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, int tiles, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, hipStream_t s);
@@ -205,7 +205,8 @@ inline int sort_digit_bits(int end_bit) { const int p = sort_passes(end_bit); re
 enum KernelId {
   K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DEPTH_KEYS, K_SORTED_SUMS, K_SORTED_OFFSETS, K_EMIT, K_SORT_HIST,
   K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_COMPACT_TOUCHED,
-  K_GATHER_RECORDS, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_COUNT
+  K_GATHER_RECORDS, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_DSORT_HIST, K_DSORT_SCAN_CHUNKS, K_DSORT_SCAN_TOP,
+  K_DSORT_SCATTER, K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);

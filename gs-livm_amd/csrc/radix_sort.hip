@@ -224,8 +224,9 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict_
 // The pairs start in (keysA, valsA) when start_in_A, else in (keysB, valsB); passes alternate.  The caller
 // picks start_in_A = (passes even) so the result always lands in (keysA, valsA).
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
-                             int n, int end_bit, bool start_in_A, hipStream_t s) {
+                             int n, int end_bit, bool start_in_A, bool is_depth_sort, hipStream_t s) {
   if (n <= 0) return hipSuccess;
+  const int kb = is_depth_sort ? (int)K_DSORT_HIST - (int)K_SORT_HIST : 0;  // profiler ids of this sort
   const int ntiles = (n + SORT_TILE - 1) / SORT_TILE;
   const int nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
   const int passes = sort_passes(end_bit);
@@ -238,19 +239,19 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
     uint32_t* vout = inA ? valsB : valsA;
     const int shift = nbits * p;
     {
-      ProfScope ps(K_SORT_HIST, s);
+      ProfScope ps(K_SORT_HIST + kb, s);
       hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(256), 0, s, kin, n, shift, nbits, sc.counts);
     }
     {
-      ProfScope ps(K_SORT_SCAN_CHUNKS, s);
+      ProfScope ps(K_SORT_SCAN_CHUNKS + kb, s);
       hipLaunchKernelGGL(k_sort_scan_chunks, dim3(nchunks), dim3(256), 0, s, sc.counts, ntiles, sc.chunk_sums);
     }
     {
-      ProfScope ps(K_SORT_SCAN_TOP, s);
+      ProfScope ps(K_SORT_SCAN_TOP + kb, s);
       hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, sc.chunk_sums, nchunks, sc.digit_base);
     }
     {
-      ProfScope ps(K_SORT_SCATTER, s);
+      ProfScope ps(K_SORT_SCATTER + kb, s);
       hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits,
                          sc.counts, sc.chunk_sums, sc.digit_base);
     }

@@ -295,6 +295,49 @@ def test_autograd_surface_several_views_one_backward(gpu_device):
         grad_close(leaves[leaf].grad.cpu().numpy(), want[k].astype(np.float32), k)
 
 
+def test_cpp_libtorch_surface_matches_c_abi_path(gpu_device):
+    """The C++/LibTorch binding GS-LIVM would link (csrc/torch_binding.cpp): RasterizeGaussiansCUDA /
+    ...BackwardCUDA give bit-identical results to the ctypes route (same C ABI underneath), and the
+    GaussianRasterizer module + autograd::Function reproduce them through loss.backward()."""
+    dev = gpu_device
+    T = G.torch_ops()
+    sc = S.make_scene(4000, 210, 130, 23, sh_degree=2)
+    t, fwd = hip_forward(sc, dev)
+    e = torch.empty(0, device=dev)
+    out = T.RasterizeGaussiansCUDA(t["bg"], t["means3D"], e, t["opacities"], t["scales"], t["rotations"], 1.0, e,
+                                   t["viewmatrix"], t["projmatrix"], sc["tanfovx"], sc["tanfovy"], 130, 210, t["shs"],
+                                   2, t["campos"], False, False)
+    assert out[0] == fwd[0]
+    for a, b in zip(out[1:5], fwd[1:5]):
+        assert torch.equal(a, b)
+    dcol, dacc = S.make_upstream_grads(210, 130, 23)
+    dc, da = torch.from_numpy(dcol).to(dev), torch.from_numpy(dacc).to(dev)
+    gb = T.RasterizeGaussiansBackwardCUDA(t["bg"], t["means3D"], out[4], e, t["scales"], t["rotations"], 1.0, e,
+                                          t["viewmatrix"], t["projmatrix"], sc["tanfovx"], sc["tanfovy"], dc, da,
+                                          t["shs"], 2, t["campos"], out[5], out[0], out[6], out[7], False)
+    ref = hip_backward(sc, t, fwd, dcol, dacc, dev)
+    names = ("dL_dmeans2D", "dL_dcolors", "dL_dopacity", "dL_dmeans3D", "dL_dcov3D", "dL_dsh", "dL_dscales",
+             "dL_drotations")
+    for n, g in zip(names, gb):
+        assert np.array_equal(g.cpu().numpy(), ref[n]), n
+    # module + autograd
+    leaves = {k: t[k].clone().requires_grad_(True) for k in ("means3D", "scales", "rotations", "opacities", "shs")}
+    st = T.GaussianRasterizationSettings(130, 210, sc["tanfovx"], sc["tanfovy"], t["bg"], 1.0, t["viewmatrix"],
+                                         t["projmatrix"], 2, t["campos"], False)
+    means2D = torch.zeros_like(leaves["means3D"], requires_grad=True)
+    color, radii, depth, acc = T.GaussianRasterizer(st).forward(leaves["means3D"], means2D, leaves["opacities"],
+                                                                shs=leaves["shs"], scales=leaves["scales"],
+                                                                rotations=leaves["rotations"])
+    assert torch.equal(color, fwd[1]) and torch.equal(radii, fwd[4]) and not radii.requires_grad
+    ((color * dc).sum() + (acc * da).sum() + depth.sum()).backward()
+    for leaf, n in (("means3D", "dL_dmeans3D"), ("scales", "dL_dscales"), ("rotations", "dL_drotations"),
+                    ("opacities", "dL_dopacity"), ("shs", "dL_dsh")):
+        assert np.array_equal(leaves[leaf].grad.cpu().numpy(), ref[n].reshape(leaves[leaf].shape)), n
+    assert np.array_equal(means2D.grad.cpu().numpy(), ref["dL_dmeans2D"])
+    vis = T.markVisible(t["means3D"], t["viewmatrix"], t["projmatrix"])
+    assert np.array_equal(vis.cpu().numpy(), O.mark_visible(sc["means3D"], sc["viewmatrix"]))
+
+
 # ----------------------------- full-size, size-independent properties -----------------------------
 @pytest.fixture(scope="module")
 def c3(gpu_device):

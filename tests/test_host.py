@@ -36,6 +36,32 @@ def test_rasterizer_argument_exclusivity():
         r(m, m, o, shs=torch.zeros(4, 1, 3), scales=m, rotations=torch.zeros(4, 4), cov3D_precomp=torch.zeros(4, 6))
 
 
+def test_cpp_operator_surface_mirrors_the_reference():
+    """csrc/torch_binding.cpp: same free functions / classes as src/gs/rasterize_points.cu + rasterizer.cu, and
+    the same std::invalid_argument rules (rasterizer.cu:161-169), exercised through pybind11 (no GPU needed)."""
+    T = G.torch_ops()
+    for name in ("RasterizeGaussiansCUDA", "RasterizeGaussiansBackwardCUDA", "markVisible",
+                 "GaussianRasterizationSettings", "GaussianRasterizer"):
+        assert hasattr(T, name), name
+    s = _settings()
+    r = T.GaussianRasterizer(T.GaussianRasterizationSettings(48, 64, s.tanfovx, s.tanfovy, s.bg, 1.0, s.viewmatrix,
+                                                            s.projmatrix, 0, s.camera_center, False))
+    m, o = torch.zeros(4, 3), torch.zeros(4, 1)
+    with pytest.raises(ValueError, match="SHs or precomputed colors"):
+        r.forward(m, m, o, scales=m, rotations=torch.zeros(4, 4))
+    with pytest.raises(ValueError, match="SHs or precomputed colors"):
+        r.forward(m, m, o, shs=torch.zeros(4, 1, 3), colors_precomp=m, scales=m, rotations=torch.zeros(4, 4))
+    with pytest.raises(ValueError, match="scale/rotation pair"):
+        r.forward(m, m, o, shs=torch.zeros(4, 1, 3))
+    with pytest.raises(ValueError, match="scale/rotation pair"):
+        r.forward(m, m, o, shs=torch.zeros(4, 1, 3), scales=m, rotations=torch.zeros(4, 4),
+                  cov3D_precomp=torch.zeros(4, 6))
+    with pytest.raises(RuntimeError, match=r"\(num_points, 3\)"):
+        T.RasterizeGaussiansCUDA(torch.ones(3), torch.zeros(4, 2), m, o, m, torch.zeros(4, 4), 1.0, torch.zeros(0),
+                                 s.viewmatrix, s.projmatrix, 1.0, 1.0, 8, 8, torch.zeros(4, 1, 3), 0, s.camera_center,
+                                 False, False)
+
+
 def test_forward_shape_error_like_reference():
     """src/gs/rasterize_points.cu:67-69"""
     with pytest.raises(ValueError, match=r"\(num_points, 3\)"):
