@@ -39,18 +39,25 @@ from gs_livm_amd import synthetic as S  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def algorithmic_bytes(P, P_vis, R, W, H, M, tiles, n_pass):
-    """SURVEY.md section 8(d) per-kernel algorithmic bytes per LAUNCH (see DESIGN.md 'Measurement')."""
+def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
+    """Algorithmic HBM bytes per LAUNCH of every kernel (DESIGN.md section 5 states each figure).
+    R = instances, R_bwd = sum over tiles of tile_last (list entries the backward has to walk)."""
     return {
-        "k_preprocess": P * (44 + 12 * M) + P * 8 + P_vis * 67,
-        "k_scan_block_sums": P * 8,
-        "k_duplicate": P * 20 + R * 12,
-        "k_sort_hist": R * 8,
-        "k_sort_scan_chunks": 0, "k_sort_scan_top": 0,
-        "k_sort_scatter": R * 24,                      # read 12 B + write 12 B per pair per pass
-        "k_tile_ranges": R * 8 + tiles * 8,
-        "k_blend_forward": R * 44 + W * H * 28,
-        "k_blend_backward": W * H * 24 + R * 40 + R * 36,
+        "k_preprocess": P * (44 + 12 * M) + P * 8 + P_vis * 77,   # in: 56 B @M=1; out: radii+tiles, 48-B splat, cov3D, depth, clamp
+        "k_scan_block_sums": (P // 256 + 1) * 8,
+        "k_depth_keys": P * 20,
+        "k_sort_hist[depth]": P * 4, "k_sort_scatter[depth]": P * 16,
+        "k_sort_scan_chunks[depth]": (P // 4096 + 1) * 2048, "k_sort_scan_top[depth]": 0,
+        "k_sorted_block_sums": P * 8,
+        "k_sorted_offsets": P * 8 + P_vis * 20 + P * 12 + P_vis * 8,
+        "k_emit": R * 8 + P_vis * 16,
+        "k_sort_hist": R * 4, "k_sort_scatter": R * 16,           # (u32 tile, u32 id): read 8 B + write 8 B per pass
+        "k_sort_scan_chunks": (R // 4096 + 1) * 2048, "k_sort_scan_top": 0,
+        "k_tile_ranges": R * 4 + tiles * 8,
+        "k_blend_forward": R * 44 + W * H * 28,                   # SURVEY.md 8(d): full lists (early exit reads fewer)
+        "k_blend_backward": W * H * 24 + R_bwd * (40 + 36),       # SURVEY.md 8(d) per-instance figures x walked entries
+        "k_compact_touched": P * 1 + P_vis * 0,
+        "k_gather_records": R_bwd * 48,
         "k_gaussian_backward": P * (108 + 12 * M) + P_vis * (111 + 12 * M) + P_vis * (64 + 12 * M),
     }
 
@@ -164,11 +171,13 @@ def main():
         P_vis = int((radii > 0).sum())
         v = G.state_views(fw[5], fw[6], fw[7], P, R, W, H)
         ln = (v["ranges"][:, 1] - v["ranges"][:, 0]).float()
-        stats = dict(P=P, P_vis=P_vis, R=R, tiles=int(ln.numel()), mean_tile_list=float(ln.mean()),
-                     max_tile_list=int(ln.max()), mean_contrib_per_pixel=float(v["n_contrib"].float().mean()))
+        R_bwd = int(v["tile_last"].long().sum())
+        stats = dict(P=P, P_vis=P_vis, R=R, R_walked_by_backward=R_bwd, tiles=int(ln.numel()),
+                     mean_tile_list=float(ln.mean()), max_tile_list=int(ln.max()),
+                     mean_contrib_per_pixel=float(v["n_contrib"].float().mean()))
     tiles = stats["tiles"]
-    n_pass = (32 + int(G.lib().gsr_higher_msb(tiles)) + 7) // 8
-    alg = algorithmic_bytes(P, P_vis, R, W, H, M, tiles, n_pass)
+    tile_bits = int(G.lib().gsr_higher_msb(tiles))
+    alg = algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles)
     kernels = {}
     for name, (ms, cnt) in prof.items():
         if cnt:
@@ -180,9 +189,8 @@ def main():
     roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
                     algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_ms=round(kernels[dom]["avg_launch_ms"], 4))
-    # whole-path figure of SURVEY.md 8(d): B_alg(fwd+bwd) / t
-    b_path = (alg["k_preprocess"] + alg["k_scan_block_sums"] + alg["k_duplicate"] + n_pass * alg["k_sort_scatter"] +
-              alg["k_tile_ranges"] + alg["k_blend_forward"] + alg["k_blend_backward"] + alg["k_gaussian_backward"])
+    # whole path: sum over kernels of (algorithmic bytes per launch x launches per step)
+    b_path = sum(alg.get(k, 0) * d["launches_per_step"] for k, d in kernels.items())
     raster_ms = sum(k["ms_per_step"] for k in kernels.values())
 
     ms_per_step = elapsed / args.steps * 1e3

@@ -297,6 +297,7 @@ class GaussianRasterizer : torch::nn::Module {
 };
 
 // ------------------------- pybind11 exposure (tests drive the C++ surface) -------------------------
+#ifndef GSR_NO_PYBIND
 namespace py = pybind11;
 
 PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
@@ -333,3 +334,4 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            py::arg("colors_precomp") = py::none(), py::arg("scales") = py::none(), py::arg("rotations") = py::none(),
            py::arg("cov3D_precomp") = py::none());
 }
+#endif  // GSR_NO_PYBIND
