@@ -186,8 +186,17 @@ def main():
                                  alg_GBps=(alg.get(name, 0) / (ms / cnt * 1e-3) / 1e9) if ms > 0 else None)
     dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
     achieved = alg[dom] / (kernels[dom]["avg_launch_ms"] * 1e-3) / 1e9
+    # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3
+    # passes, corrected as tools/pmc_summary.py documents): PMC collection cannot run inside a timed bench, so the
+    # figure comes from the committed summary of the same command on the same build (profiles/README.md).
+    traffic = None
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as fh:
+            traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
+    except (OSError, ValueError):
+        pass
     roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=None,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_ms=round(kernels[dom]["avg_launch_ms"], 4))
     # whole path: sum over kernels of (algorithmic bytes per launch x launches per step)
     b_path = sum(alg.get(k, 0) * d["launches_per_step"] for k, d in kernels.items())

@@ -1,6 +1,6 @@
 import sys
 import numpy as np, torch
-sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import os; ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import gs_livm_amd as G
 from gs_livm_amd import synthetic as S
 from oracle import oracle as O
