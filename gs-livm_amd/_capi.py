@@ -11,7 +11,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgsraster_hip.so")
+LIB_PATH = os.environ.get("GSR_LIB", os.path.join(_HERE, "libgsraster_hip.so"))  # GSR_LIB: A/B experiment builds
 
 ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 

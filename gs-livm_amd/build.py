@@ -13,7 +13,9 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
-LIB = os.path.join(HERE, "libgsraster_hip.so")
+# experiment hooks (A/B builds): extra flags for render.hip and a suffix for the library / object names
+SUFFIX = os.environ.get("GSR_LIB_SUFFIX", "")
+LIB = os.path.join(HERE, "libgsraster_hip%s.so" % SUFFIX)
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
@@ -24,7 +26,9 @@ COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno
 UNITS = {
     "preprocess.hip": ["-ffp-contract=off"],
     "radix_sort.hip": [],
-    "render.hip": ["-ffp-contract=fast"],
+    # SLP vectorisation packs the scalar f32 math into v_pk_* and splits the fused v_add_f32_dpp reductions
+    # into mov_dpp + pk_add: measured 9 % slower on k_blend_backward, so it is off for the blend kernels.
+    "render.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"] + os.environ.get("GSR_EXTRA_RENDER_FLAGS", "").split(),
     "api.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "gsr_internal.hpp"), os.path.join(ROOT, "include", "gsraster.h")]
@@ -45,7 +49,7 @@ def build_lib(force=False, verbose=False):
     objs, jobs = [], []
     for src, extra in UNITS.items():
         s = os.path.join(CSRC, src)
-        o = os.path.join(CSRC, src.replace(".hip", ".o"))
+        o = os.path.join(CSRC, src.replace(".hip", "%s.o" % SUFFIX))
         objs.append(o)
         if force or _stale(o, [s] + HEADERS + [os.path.abspath(__file__)]):
             jobs.append([HIPCC] + COMMON + extra + ["-c", s, "-o", o])

@@ -35,10 +35,11 @@ __device__ __forceinline__ float dpp_get(float v) {
 // Sum over the 64 lanes of a wave; the total is valid in lanes 48..63 (read it from lane 63).
 // Fixed association order => deterministic.
 __device__ __forceinline__ float wave_sum_to_hi(float v) {
-  v += dpp_get<0xB1, 0xF, 0xF>(v);   // quad_perm [1,0,3,2]
-  v += dpp_get<0x4E, 0xF, 0xF>(v);   // quad_perm [2,3,0,1]
-  v += dpp_get<0x124, 0xF, 0xF>(v);  // row_ror:4
-  v += dpp_get<0x128, 0xF, 0xF>(v);  // row_ror:8  -> every lane of a 16-lane row holds the row sum
+  v += __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0xB1, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x4E, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x124, 0xF, 0xF, true));
+  v += __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), 0x128, 0xF, 0xF, true));
+  // every lane of a 16-lane row now holds the row sum
   v += dpp_get<0x142, 0xA, 0xF>(v);  // row_bcast:15 into rows 1 and 3
   v += dpp_get<0x143, 0xC, 0xF>(v);  // row_bcast:31 into rows 2 and 3
   return v;
@@ -57,11 +58,17 @@ __device__ __forceinline__ void swap_add16(float& a, float& b) {
   const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
   a = __uint_as_float(r[0]) + __uint_as_float(r[1]);  // rows 0,2: a's row pairs; rows 1,3: b's row pairs
 }
+// quad_perm / row_ror read a valid lane for every lane, so `old` is irrelevant: passing the source itself lets
+// the compiler fold the move into a single v_add_f32_dpp (no zero-initialised temporary).
+template <int CTRL>
+__device__ __forceinline__ float dpp_full(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
 __device__ __forceinline__ float row_allsum(float v) {
-  v += dpp_get<0xB1, 0xF, 0xF>(v);   // quad_perm [1,0,3,2]
-  v += dpp_get<0x4E, 0xF, 0xF>(v);   // quad_perm [2,3,0,1]
-  v += dpp_get<0x124, 0xF, 0xF>(v);  // row_ror:4
-  v += dpp_get<0x128, 0xF, 0xF>(v);  // row_ror:8
+  v += dpp_full<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_full<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_full<0x124>(v);  // row_ror:4
+  v += dpp_full<0x128>(v);  // row_ror:8
   return v;
 }
 __device__ __forceinline__ void wave_sum8(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
@@ -240,6 +247,8 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   float T = T_final;
   float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, aacc = 0.f;  // accum_rec, accum_acc_rec
   float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_acc = 0.f;
+  // entries at or beyond the quad's own last contributor cannot receive gradient from this wave
+  const int quad_last = (int)__builtin_amdgcn_readfirstlane(wave_max_u32((uint32_t)lastc));
 
   for (int base = 0; base < n; base += CHUNK) {
     const int k = base + tid;  // k-th entry counted from the back of [0, n)
@@ -272,48 +281,52 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         m &= m - 1;
         const int jj = lw * 64 + bpos;
         const int pos = n - 1 - (base + jj);  // 0-based index in the tile list == `contributor` after decrement
+        if (pos >= quad_last) {                // wave-uniform: nothing to do for this quad, publish zeros
+          if ((lane & 15) == 0) {
+            float2* p2 = reinterpret_cast<float2*>(sPart[w][jj]);
+            p2[lane >> 4] = make_float2(0.f, 0.f);
+            if (lane == 48) sPart[w][jj][8] = 0.f;
+          }
+          continue;
+        }
         const float4 a = sA[jj];
         const float4 b = sB[jj];
         const float blue = sBlue[jj];
         const float dx = a.x - pfx, dy = a.y - pfy;
         const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-        const float G = __expf(power);
-        const float alpha = fminf(0.99f, b.y * G);
-        const bool ok = (pos < lastc) && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-        float g0 = 0.f, g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f, g5 = 0.f, g6 = 0.f, g7 = 0.f, g8 = 0.f;
+        const float Graw = __expf(power);
+        const float araw = fminf(0.99f, b.y * Graw);
+        const bool ok = (pos < lastc) && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
         if (__ballot(ok) != 0ull) {
-          const float om = 1.0f - alpha;
-          const float rom = __builtin_amdgcn_rcpf(om);
-          const float Tn = T * rom;  // T / (1 - alpha)
-          const float dch = alpha * Tn;
-          const float n0 = last_alpha * lc0 + (1.f - last_alpha) * ar0;
-          const float n1 = last_alpha * lc1 + (1.f - last_alpha) * ar1;
-          const float n2 = last_alpha * lc2 + (1.f - last_alpha) * ar2;
-          const float nacc = last_alpha * last_acc + (1.f - last_alpha) * aacc;
-          float dL_dalpha = (b.z - n0) * dp0 + (b.w - n1) * dp1 + (blue - n2) * dp2 + (1.0f - nacc) * dacc;
-          dL_dalpha *= Tn;
+          // Branch-free per lane: a lane that does not take this splat runs the same code with alpha = 0 and
+          // G = 0.  Every gradient term carries a factor alpha or G, so its partials are exact zeros, and the
+          // recurrence state it leaves behind, (accum' = n, last_alpha' = 0, last_color' = c), reproduces
+          // n' = 0*c + 1*n = n bit for bit at the next visit -- identical to not having visited, without the
+          // save/restore traffic a divergent `if (ok)` costs (T * rcp(1 - 0) = T exactly).
+          const float alpha = ok ? araw : 0.0f;
+          const float G = ok ? Graw : 0.0f;
+          const float rom = __builtin_amdgcn_rcpf(1.0f - alpha);
+          T = T * rom;  // T / (1 - alpha)
+          const float dch = alpha * T;
+          const float oml = 1.f - last_alpha;
+          ar0 = last_alpha * lc0 + oml * ar0;
+          ar1 = last_alpha * lc1 + oml * ar1;
+          ar2 = last_alpha * lc2 + oml * ar2;
+          aacc = last_alpha * last_acc + oml * aacc;
+          float dL_dalpha = (b.z - ar0) * dp0 + (b.w - ar1) * dp1 + (blue - ar2) * dp2 + (1.0f - aacc) * dacc;
+          dL_dalpha *= T;
           dL_dalpha += (-T_final * rom) * bg_dot;
+          lc0 = b.z; lc1 = b.w; lc2 = blue; last_acc = 1.0f;
+          last_alpha = alpha;
           // Factors common to every pixel of the splat (opacity, -0.5, 0.5*W, 0.5*H) are applied once per
           // instance when the four quads are combined, not per pixel.
           const float gdx = G * dx, gdy = G * dy;
-          const float dG_ddelx = -gdx * a.z - gdy * a.w;
-          const float dG_ddely = -gdy * b.x - gdx * a.w;
-          if (ok) {
-            g0 = dch * dp0;
-            g1 = dch * dp1;
-            g2 = dch * dp2;
-            g3 = dL_dalpha * dG_ddelx;
-            g4 = dL_dalpha * dG_ddely;
-            const float sx = dL_dalpha * gdx, sy = dL_dalpha * gdy;
-            g5 = sx * dx;
-            g6 = sx * dy;
-            g7 = sy * dy;
-            g8 = G * dL_dalpha;
-            T = Tn;
-            ar0 = n0; ar1 = n1; ar2 = n2; aacc = nacc;
-            lc0 = b.z; lc1 = b.w; lc2 = blue; last_acc = 1.0f;
-            last_alpha = alpha;
-          }
+          const float sx = dL_dalpha * gdx, sy = dL_dalpha * gdy;
+          const float g0 = dch * dp0, g1 = dch * dp1, g2 = dch * dp2;
+          const float g3 = -sx * a.z - sy * a.w;  // dL_dalpha * dG_ddelx
+          const float g4 = -sy * b.x - sx * a.w;  // dL_dalpha * dG_ddely
+          const float g5 = sx * dx, g6 = sx * dy, g7 = sy * dy;
+          float g8 = G * dL_dalpha;
           float w0, w1;
           wave_sum8(g0, g1, g2, g3, g4, g5, g6, g7, w0, w1);
           g8 = wave_sum_to_hi(g8);
