@@ -5,10 +5,12 @@ activation / Adam step that BASELINE config C3 names) on synthetic data.
     python bench.py [--gpus N] [--steps K] [--warmup W] [--workload C3|C2|C1]
 
 One STEP = one optimiser iteration over one 1920x1080 view per GPU of the C3 scene (2 M Gaussians, seed 3,
-SH degree 0 -- the product setting): activations (sigmoid / exp / normalize, torch)
+SH degree 0 -- the product setting): activations (sigmoid / exp / normalize / cat)
 -> GaussianRasterizer forward (HIP, through the C ABI) -> synthetic upstream gradients dL/dcolor, dL/dacc
- -> rasterizer backward (HIP) -> activation backward -> Adam step (torch, reference learning
-rates).  Inputs are resident in HBM before the timed region.  value = Mpixels/s of the whole job.
+ injected into autograd -> rasterizer backward (HIP) -> activation backward -> Adam step with the
+reference's groups / learning rates.  Activations and Adam run as the fused HIP kernels of csrc/optimizer.hip
+(SURVEY.md 8(f) "next" row 1) unless --torch-optimizer selects the reference's separate Torch ops.
+Inputs are resident in HBM before the timed region.  value = Mpixels/s of the whole job.
 
 N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): rank r renders view r of the same scene
 (yaw offsets of SURVEY.md 8(d)); per step the optimiser owner (rank 0) broadcasts the flat parameter buffer,
@@ -71,6 +73,11 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adam", action="store_true", help="time rasterizer fwd+bwd only (diagnostic)")
+    ap.add_argument("--torch-optimizer", action="store_true",
+                    help="activations / Adam as separate Torch ops (what the reference does) instead of the fused kernels")
+    ap.add_argument("--forward-only", action="store_true", help="BASELINE C2 style: colour+depth+silhouette forward only")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="gloo = rehearsal of the multi-rank control flow (collectives staged through the host)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -78,13 +85,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    local_rank %= max(1, torch.cuda.device_count())  # a gloo rehearsal may put several ranks on one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
     n_gpus = world if world > 1 else 1
     if args.gpus != n_gpus and rank == 0:
         print("note: --gpus %d but WORLD_SIZE %d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
@@ -104,12 +115,20 @@ def main():
     if rank == 0:
         params.load({k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in pre.items()})
     MV.broadcast_gaussians(params, src=0)
-    leaves = {k: torch.nn.Parameter(v) for k, v in params.views.items()}
+    v = params.views
+    model = G.GaussianParameters(v["means3D"], v["features_dc"], v["features_rest"], v["scales"], v["rotations"],
+                                 v["opacities"])
+    leaves = dict(means3D=model._xyz, features_dc=model._features_dc, features_rest=model._features_rest,
+                  scales=model._scaling, rotations=model._rotation, opacities=model._opacity)
     for k, p in leaves.items():
         p.grad = grads.views[k]  # autograd accumulates in place -> gradients live in one flat buffer too
-    # reference learning rates (config/basic_common.yaml:55-62; groups as src/gs/gaussian.cu:401-427, eps 1e-15)
-    lrs = dict(means3D=1.6e-4, shs=2.5e-3, opacities=5e-2, scales=5e-3, rotations=1e-3)
-    opt = torch.optim.Adam([{"params": [leaves[k]], "lr": lrs[k]} for k in leaves], eps=1e-15, fused=True)
+    # groups / learning rates of GaussianModel::Training_setup (src/gs/gaussian.cu:396-428) with the values of
+    # config/basic_common.yaml:54-62, eps 1e-15
+    groups = [gr for gr in model.param_groups() if gr["params"][0].numel()]
+    if args.torch_optimizer:
+        opt = torch.optim.Adam(groups, eps=1e-15, fused=True)
+    else:
+        opt = G.FusedAdam(groups, eps=1e-15)
 
     bg = torch.ones(3, device=dev)
     settings = G.GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], bg, 1.0,
@@ -122,22 +141,34 @@ def main():
     means2D = torch.zeros((P, 3), device=dev, requires_grad=True)  # gradient sink, as render_utils.cuh:39-40
 
     def activated():
-        return (leaves["means3D"], torch.sigmoid(leaves["opacities"]), torch.exp(leaves["scales"]),
-                torch.nn.functional.normalize(leaves["rotations"], dim=1), leaves["shs"])
+        if args.torch_optimizer:  # the reference's getters as separate Torch ops (gaussian.cuh:40-54)
+            return (model._xyz, torch.sigmoid(model._opacity), torch.exp(model._scaling),
+                    torch.nn.functional.normalize(model._rotation, dim=1),
+                    torch.cat([model._features_dc, model._features_rest], 1))
+        return model.activated()
 
     def step():
         if n_gpus > 1:
             MV.broadcast_gaussians(params, src=0)
         xyz, op, sc, rot, shs = activated()
+        if args.forward_only:
+            with torch.no_grad():
+                raster(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
+            return
         color, radii, depth, acc = raster(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
-        loss = (color * wc).sum() + (acc * wa).sum()
-        grads.flat.zero_()
         means2D.grad = None
-        loss.backward()
+        if args.torch_optimizer:
+            grads.flat.zero_()
+        # upstream gradients injected directly (SURVEY.md 8(d) backward seeds): dL/dcolor = wc, dL/dacc = wa
+        torch.autograd.backward([color, acc], [wc, wa])
         if n_gpus > 1:
             MV.reduce_gradients(grads, dst=0)
-        if rank == 0 and not args.no_adam:
-            opt.step()
+        if args.no_adam:
+            grads.flat.zero_()
+        elif rank == 0:
+            opt.step()  # FusedAdam also clears the gradients it consumed
+        elif not args.torch_optimizer:
+            grads.flat.zero_()
 
     def barrier():
         torch.cuda.synchronize()
@@ -157,7 +188,7 @@ def main():
     G.profile_enable(False)
     prof = G.profile_read()
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
@@ -205,14 +236,17 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     mpix = n_gpus * W * H * args.steps / elapsed / 1e6
     out = {
-        "metric": "rasterizer fwd+bwd Mpixels/s @%dx%d, %d Gaussians (ms_per_step = ms/frame)" % (W, H, P),
+        "metric": "rasterizer %s Mpixels/s @%dx%d, %d Gaussians (ms_per_step = ms/frame)" %
+                  ("fwd" if args.forward_only else "fwd+bwd", W, H, P),
         "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d Gaussians, %dx%d, SH degree %d, 1 view per GPU, fwd+bwd + Adam step" %
-                               (args.workload, P, W, H, D),
+        "config": {"workload": "%s: %d Gaussians, %dx%d, SH degree %d, 1 view per GPU, %s" %
+                               (args.workload, P, W, H, D,
+                                "forward only" if args.forward_only else "fwd+bwd + Adam step"),
                    "views_per_step": n_gpus, "parallelism": "view-parallel x%d" % n_gpus,
-                   "adam_in_step": not args.no_adam},
+                   "adam_in_step": not (args.no_adam or args.forward_only),
+                   "optimizer": "torch ops" if args.torch_optimizer else "fused activations + fused Adam (HIP)"},
         "fps": round(1e3 / ms_per_step * n_gpus, 2),
         "roofline": roofline,
         "whole_path": {"kernel_ms_per_step": round(raster_ms, 4), "algorithmic_GB_per_step": round(b_path / 1e9, 3),
@@ -222,7 +256,7 @@ def main():
         "workload_stats": stats,
     }
 
-    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not args.forward_only:
         out["cpu_baseline"] = cpu_baseline(g, cam, dcol, dacc, W, H, D)
     if rank == 0:
         print(json.dumps(out))

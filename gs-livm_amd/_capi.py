@@ -34,7 +34,7 @@ _lib = None
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_bytes", "gsr_image_bytes",
            "gsr_binning_bytes", "gsr_geometry_view_of", "gsr_binning_view_of", "gsr_image_view_of",
            "gsr_higher_msb", "gsr_last_error", "gsr_abi_version", "gsr_kernel_count", "gsr_kernel_name",
-           "gsr_profile_enable", "gsr_profile_read")
+           "gsr_profile_enable", "gsr_profile_read", "gsr_activate", "gsr_activate_backward", "gsr_adam_step")
 
 
 def lib():
@@ -74,6 +74,13 @@ def lib():
     L.gsr_profile_enable.argtypes = [ci]
     L.gsr_profile_read.restype = ci
     L.gsr_profile_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(ci)]
+    L.gsr_activate.restype = ci
+    L.gsr_activate.argtypes = [ci, ci] + [vp] * 9 + [vp]
+    L.gsr_activate_backward.restype = ci
+    L.gsr_activate_backward.argtypes = [ci, ci] + [vp] * 12 + [vp]
+    L.gsr_adam_step.restype = ci
+    L.gsr_adam_step.argtypes = [ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz),
+                                C.POINTER(cf), cf, cf, cf, ci, ci, vp]
     _lib = L
     return L
 
@@ -243,3 +250,42 @@ def profile_read():
     cnt = (C.c_int * n)()
     _check(L.gsr_profile_read(n, ms, cnt))
     return {L.gsr_kernel_name(i).decode(): (float(ms[i]), int(cnt[i])) for i in range(n)}
+
+
+# ---- "next" row: fused activations + Adam (include/gsraster.h; csrc/optimizer.hip) ----
+def activate(scaling_raw, rotation_raw, opacity_raw, features_dc, features_rest):
+    """GaussianModel's getters in one launch (include/gs/gs/gaussian.cuh:40-54):
+    returns (scales [P,3], rotations [P,4], opacities [P,1], shs [P,M,3])."""
+    P = int(scaling_raw.size(0))
+    M = 1 + (int(features_rest.size(1)) if features_rest is not None and features_rest.numel() else 0)
+    f32 = dict(dtype=torch.float32, device=scaling_raw.device)
+    scales, rot = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32)
+    opac, shs = torch.empty((P, 1), **f32), torch.empty((P, M, 3), **f32)
+    _check(lib().gsr_activate(P, M, _ptr(scaling_raw), _ptr(rotation_raw), _ptr(opacity_raw), _ptr(features_dc),
+                              _ptr(features_rest), _ptr(scales), _ptr(rot), _ptr(opac), _ptr(shs), _stream()))
+    return scales, rot, opac, shs
+
+
+def activate_backward(rotation_raw, scales, opacities, g_scales, g_rot, g_opac, g_shs):
+    """Chain rule of `activate`; returns grads w.r.t. (_scaling, _rotation, _opacity, _features_dc, _features_rest)."""
+    P, M = int(scales.size(0)), int(g_shs.size(1))
+    f32 = dict(dtype=torch.float32, device=scales.device)
+    gs, gr, go = torch.empty((P, 3), **f32), torch.empty((P, 4), **f32), torch.empty((P, 1), **f32)
+    gdc, grest = torch.empty((P, 1, 3), **f32), torch.empty((P, M - 1, 3), **f32)
+    _check(lib().gsr_activate_backward(P, M, _ptr(rotation_raw), _ptr(scales), _ptr(opacities), _ptr(g_scales),
+                                       _ptr(g_rot), _ptr(g_opac), _ptr(g_shs), _ptr(gs), _ptr(gr), _ptr(go),
+                                       _ptr(gdc), _ptr(grest), _stream()))
+    return gs, gr, go, gdc, grest
+
+
+def adam_step(params, grads, exp_avg, exp_avg_sq, lrs, beta1, beta2, eps, step, zero_grads=True):
+    """torch::optim::Adam::step for up to 8 tensors in one launch (in place)."""
+    n = len(params)
+    VP = C.c_void_p * n
+    arr = lambda ts: VP(*[t.data_ptr() if t.numel() else None for t in ts])  # noqa: E731
+    numel = (C.c_size_t * n)(*[int(t.numel()) for t in params])
+    lr = (C.c_float * n)(*[float(x) for x in lrs])
+    for t in list(params) + list(grads) + list(exp_avg) + list(exp_avg_sq):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+    _check(lib().gsr_adam_step(n, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel, lr, float(beta1),
+                               float(beta2), float(eps), int(step), int(bool(zero_grads)), _stream()))

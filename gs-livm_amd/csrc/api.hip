@@ -59,7 +59,8 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_preprocess", "k_scan_block_sums", "k_depth_keys", "k_sorted_block_sums", "k_sorted_offsets", "k_emit",
     "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top", "k_sort_scatter", "k_tile_ranges", "k_blend_forward",
     "k_blend_backward", "k_compact_touched", "k_gather_records", "k_gaussian_backward", "k_mark_visible", "k_sort_hist[depth]",
-    "k_sort_scan_chunks[depth]", "k_sort_scan_top[depth]", "k_sort_scatter[depth]"};
+    "k_sort_scan_chunks[depth]", "k_sort_scan_top[depth]", "k_sort_scatter[depth]", "k_activate",
+    "k_activate_backward", "k_adam"};
 
 extern "C" {
 
@@ -255,6 +256,52 @@ int gsr_mark_visible(int P, const float* means3D, const float* viewmatrix, const
   if (P == 0) return GSR_OK;
   if (!means3D || !viewmatrix || !present) return fail(GSR_ERR_INVALID_ARGUMENT, "null pointer");
   HIP_TRY(launch_mark_visible(P, means3D, viewmatrix, present, (hipStream_t)stream_));
+  return GSR_OK;
+}
+
+int gsr_activate(int P, int M, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                 const float* features_dc, const float* features_rest, float* scales, float* rotations,
+                 float* opacities, float* shs, void* stream_) {
+  g_err[0] = 0;
+  if (P < 0 || M < 1 || M > 16) return fail(GSR_ERR_INVALID_ARGUMENT, "bad P/M");
+  if (P == 0) return GSR_OK;
+  if (!scaling_raw || !rotation_raw || !opacity_raw || !features_dc || (M > 1 && !features_rest) || !scales ||
+      !rotations || !opacities || !shs)
+    return fail(GSR_ERR_INVALID_ARGUMENT, "null pointer");
+  HIP_TRY(launch_activate(P, M, scaling_raw, rotation_raw, opacity_raw, features_dc, features_rest, scales, rotations,
+                          opacities, shs, (hipStream_t)stream_));
+  return GSR_OK;
+}
+
+int gsr_activate_backward(int P, int M, const float* rotation_raw, const float* scales, const float* opacities,
+                          const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
+                          const float* dL_dshs, float* dL_dscaling_raw, float* dL_drotation_raw,
+                          float* dL_dopacity_raw, float* dL_dfeatures_dc, float* dL_dfeatures_rest, void* stream_) {
+  g_err[0] = 0;
+  if (P < 0 || M < 1 || M > 16) return fail(GSR_ERR_INVALID_ARGUMENT, "bad P/M");
+  if (P == 0) return GSR_OK;
+  if (!rotation_raw || !scales || !opacities || !dL_dscales || !dL_drotations || !dL_dopacities || !dL_dshs ||
+      !dL_dscaling_raw || !dL_drotation_raw || !dL_dopacity_raw || !dL_dfeatures_dc || (M > 1 && !dL_dfeatures_rest))
+    return fail(GSR_ERR_INVALID_ARGUMENT, "null pointer");
+  HIP_TRY(launch_activate_backward(P, M, rotation_raw, scales, opacities, dL_dscales, dL_drotations, dL_dopacities,
+                                   dL_dshs, dL_dscaling_raw, dL_drotation_raw, dL_dopacity_raw, dL_dfeatures_dc,
+                                   dL_dfeatures_rest, (hipStream_t)stream_));
+  return GSR_OK;
+}
+
+int gsr_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const size_t* numel, const float* lr, float beta1, float beta2, float eps,
+                  int step, int zero_grads, void* stream_) {
+  g_err[0] = 0;
+  if (n_tensors < 0 || n_tensors > 8) return fail(GSR_ERR_INVALID_ARGUMENT, "1..8 tensors per call");
+  if (step < 1) return fail(GSR_ERR_INVALID_ARGUMENT, "step counts from 1");
+  if (n_tensors == 0) return GSR_OK;
+  if (!params || !grads || !exp_avg || !exp_avg_sq || !numel || !lr) return fail(GSR_ERR_INVALID_ARGUMENT, "null array");
+  for (int k = 0; k < n_tensors; k++)
+    if (numel[k] && (!params[k] || !grads[k] || !exp_avg[k] || !exp_avg_sq[k]))
+      return fail(GSR_ERR_INVALID_ARGUMENT, "null tensor pointer");
+  HIP_TRY(launch_adam(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, step, zero_grads,
+                      (hipStream_t)stream_));
   return GSR_OK;
 }
 

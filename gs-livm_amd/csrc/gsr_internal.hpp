@@ -196,6 +196,18 @@ hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningS
                                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                                     float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);
 hipError_t launch_mark_visible(int P, const float* means3D, const float* view, unsigned char* present, hipStream_t s);
+// optimizer.hip ("next" row: fused activations + Adam)
+hipError_t launch_activate(int P, int M, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                           const float* f_dc, const float* f_rest, float* scales, float* rotations, float* opacities,
+                           float* shs, hipStream_t s);
+hipError_t launch_activate_backward(int P, int M, const float* rotation_raw, const float* scales,
+                                    const float* opacities, const float* g_scales, const float* g_rot,
+                                    const float* g_opac, const float* g_shs, float* g_scaling_raw,
+                                    float* g_rotation_raw, float* g_opacity_raw, float* g_f_dc, float* g_f_rest,
+                                    hipStream_t s);
+hipError_t launch_adam(int n, float* const* params, float* const* grads, float* const* exp_avg,
+                       float* const* exp_avg_sq, const size_t* numel, const float* lr, float beta1, float beta2,
+                       float eps, int step, int zero_grads, hipStream_t s);
 
 inline int sort_passes(int end_bit) { return (end_bit + 7) / 8; }
 // digit width: the key bits are split evenly over the passes (13 tile bits -> 7 + 6, 32 depth bits -> 4 x 8)
@@ -206,7 +218,7 @@ enum KernelId {
   K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DEPTH_KEYS, K_SORTED_SUMS, K_SORTED_OFFSETS, K_EMIT, K_SORT_HIST,
   K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_COMPACT_TOUCHED,
   K_GATHER_RECORDS, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_DSORT_HIST, K_DSORT_SCAN_CHUNKS, K_DSORT_SCAN_TOP,
-  K_DSORT_SCATTER, K_COUNT
+  K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);

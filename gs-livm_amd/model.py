@@ -1,0 +1,109 @@
+"""Host-side mirror of the pieces of GaussianModel that sit either side of the rasterizer, on the fused
+kernels of csrc/optimizer.hip (SURVEY.md section 8(f) "next" row 1):
+
+  * `FusedActivations` -- the getters Get_scaling / Get_rotation / Get_opacity / Get_features
+    (include/gs/gs/gaussian.cuh:40-54) as ONE autograd node instead of five Torch ops;
+  * `GaussianParameters` -- the six leaf tensors with those getter names;
+  * `FusedAdam` -- torch::optim::Adam as the reference configures it (src/gs/gaussian.cu:396-428: one group
+    per leaf, eps 1e-15, betas (0.9, 0.999), no weight decay) stepping every group in one launch and clearing
+    the gradients it consumed (step + zero_grad, src/liw/lioOptimization.cpp:1831-1832).
+"""
+import torch
+
+from . import _capi
+
+
+class FusedActivations(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, scaling_raw, rotation_raw, opacity_raw, features_dc, features_rest):
+        scales, rot, opac, shs = _capi.activate(scaling_raw.contiguous(), rotation_raw.contiguous(),
+                                                opacity_raw.contiguous(), features_dc.contiguous(),
+                                                features_rest.contiguous())
+        ctx.save_for_backward(rotation_raw, scales, opac)
+        return scales, rot, opac, shs
+
+    @staticmethod
+    def backward(ctx, g_scales, g_rot, g_opac, g_shs):
+        rotation_raw, scales, opac = ctx.saved_tensors
+        z = torch.zeros_like
+        g_scales = z(scales) if g_scales is None else g_scales.contiguous()
+        g_rot = z(rotation_raw) if g_rot is None else g_rot.contiguous()
+        g_opac = z(opac) if g_opac is None else g_opac.contiguous()
+        assert g_shs is not None
+        return _capi.activate_backward(rotation_raw.contiguous(), scales, opac, g_scales, g_rot, g_opac,
+                                       g_shs.contiguous())
+
+
+class GaussianParameters(torch.nn.Module):
+    """The leaf tensors of GaussianModel (include/gs/gs/gaussian.cuh:107-119) and its getters."""
+
+    def __init__(self, xyz, features_dc, features_rest, scaling, rotation, opacity):
+        super().__init__()
+        P = torch.nn.Parameter
+        self._xyz, self._features_dc, self._features_rest = P(xyz), P(features_dc), P(features_rest)
+        self._scaling, self._rotation, self._opacity = P(scaling), P(rotation), P(opacity)
+
+    def activated(self):
+        """(xyz, opacity [P,1], scales, rotations, shs) through one fused node."""
+        scales, rot, opac, shs = FusedActivations.apply(self._scaling, self._rotation, self._opacity,
+                                                        self._features_dc, self._features_rest)
+        return self._xyz, opac, scales, rot, shs
+
+    # reference getter names (each call runs the fused node; use activated() to get all at once)
+    def Get_xyz(self):
+        return self._xyz
+
+    def Get_opacity(self):
+        return self.activated()[1]
+
+    def Get_scaling(self):
+        return self.activated()[2]
+
+    def Get_rotation(self):
+        return self.activated()[3]
+
+    def Get_features(self):
+        return self.activated()[4]
+
+    def param_groups(self, position_lr=0.0005, feature_lr=0.001, opacity_lr=0.025, scaling_lr=0.0025,
+                     rotation_lr=0.0025, spatial_lr_scale=1.0):
+        """Groups and learning rates of GaussianModel::Training_setup (src/gs/gaussian.cu:396-428) with the
+        defaults of config/basic_common.yaml:54-62."""
+        return [
+            {"params": [self._xyz], "lr": position_lr * spatial_lr_scale},
+            {"params": [self._features_dc], "lr": feature_lr},
+            {"params": [self._features_rest], "lr": feature_lr / 20.0},
+            {"params": [self._scaling], "lr": scaling_lr * spatial_lr_scale},
+            {"params": [self._rotation], "lr": rotation_lr},
+            {"params": [self._opacity], "lr": opacity_lr},
+        ]
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (no weight decay / amsgrad), all groups in ONE kernel launch."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-15):
+        super().__init__(params, dict(lr=lr, betas=betas, eps=eps))
+        self._step = 0
+
+    @torch.no_grad()
+    def step(self, zero_grads=True):
+        ps, gs, ms, vs, lrs = [], [], [], [], []
+        betas = eps = None
+        for group in self.param_groups:
+            for p in group["params"]:
+                if p.grad is None or p.numel() == 0:
+                    continue
+                st = self.state[p]
+                if not st:
+                    st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                    st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                assert betas in (None, group["betas"]) and eps in (None, group["eps"]), \
+                    "FusedAdam: one (betas, eps) for all groups, as the reference configures it"
+                betas, eps = group["betas"], group["eps"]
+                ps.append(p); gs.append(p.grad); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
+                lrs.append(group["lr"])
+        self._step += 1
+        for i in range(0, len(ps), 8):
+            _capi.adam_step(ps[i:i + 8], gs[i:i + 8], ms[i:i + 8], vs[i:i + 8], lrs[i:i + 8], betas[0], betas[1],
+                            eps, self._step, zero_grads)

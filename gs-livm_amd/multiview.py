@@ -15,9 +15,11 @@ from collections import OrderedDict
 import torch
 import torch.distributed as dist
 
-# parameter groups in buffer order: name -> trailing shape as a function of M
-_LAYOUT = OrderedDict([("means3D", lambda M: (3,)), ("scales", lambda M: (3,)), ("rotations", lambda M: (4,)),
-                       ("opacities", lambda M: (1,)), ("shs", lambda M: (M, 3))])
+# parameter groups in buffer order (the six leaves of GaussianModel, include/gs/gs/gaussian.cuh:107-119):
+# name -> trailing shape as a function of M
+_LAYOUT = OrderedDict([("means3D", lambda M: (3,)), ("features_dc", lambda M: (1, 3)),
+                       ("features_rest", lambda M: (M - 1, 3)), ("scales", lambda M: (3,)),
+                       ("rotations", lambda M: (4,)), ("opacities", lambda M: (1,))])
 
 
 def floats_per_gaussian(M):
@@ -26,7 +28,8 @@ def floats_per_gaussian(M):
 
 class GaussianBuffer:
     """One contiguous f32 buffer holding every per-Gaussian parameter group as SoA blocks
-    [means3D | scales | rotations | opacities | shs]; `views` are zero-copy tensors into it."""
+    [means3D | features_dc | features_rest | scales | rotations | opacities]; `views` are zero-copy tensors
+    into it."""
 
     def __init__(self, P, M, device, dtype=torch.float32):
         self.P, self.M = int(P), int(M)
@@ -43,8 +46,14 @@ class GaussianBuffer:
         assert off == self.flat.numel()
 
     def load(self, arrays):
+        """arrays: dict with the view names; "shs" [P,M,3] may stand in for features_dc + features_rest."""
+        arrays = dict(arrays)
+        if "shs" in arrays and "features_dc" not in arrays:
+            shs = torch.as_tensor(arrays["shs"])
+            arrays["features_dc"], arrays["features_rest"] = shs[:, :1], shs[:, 1:]
         for name, v in self.views.items():
-            v.copy_(torch.as_tensor(arrays[name]).reshape(v.shape))
+            if v.numel():
+                v.copy_(torch.as_tensor(arrays[name]).reshape(v.shape))
         return self
 
     def nbytes(self):
@@ -56,10 +65,22 @@ def shard_views(n_views, rank, world_size):
     return list(range(rank, n_views, world_size))
 
 
+def _collective(t, fn, group):
+    """Runs fn(tensor) on `t`.  RCCL ("nccl") works on device memory directly; the gloo rehearsal backend
+    (CPU tests, single-GPU dry runs of the multi-rank control flow) is staged through host memory."""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        h = t.cpu()
+        fn(h)
+        t.copy_(h)
+    else:
+        fn(t)
+
+
 def broadcast_gaussians(buf, src=0, group=None):
     """Owner -> replicas: one collective on the flat parameter buffer."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
-        dist.broadcast(buf.flat if isinstance(buf, GaussianBuffer) else buf, src=src, group=group)
+        _collective(buf.flat if isinstance(buf, GaussianBuffer) else buf,
+                    lambda x: dist.broadcast(x, src=src, group=group), group)
     return buf
 
 
@@ -68,7 +89,7 @@ def reduce_gradients(grad, dst=0, group=None, all_ranks=False):
     t = grad.flat if isinstance(grad, GaussianBuffer) else grad
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         if all_ranks:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+            _collective(t, lambda x: dist.all_reduce(x, op=dist.ReduceOp.SUM, group=group), group)
         else:
-            dist.reduce(t, dst=dst, op=dist.ReduceOp.SUM, group=group)
+            _collective(t, lambda x: dist.reduce(x, dst=dst, op=dist.ReduceOp.SUM, group=group), group)
     return grad

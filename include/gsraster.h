@@ -127,6 +127,27 @@ int gsr_image_view_of(char* image_buffer, int width, int height, gsr_image_view*
 /* getHigherMsb (rasterizer_impl.cu:35-48): number of tile-id bits the sort covers. */
 uint32_t gsr_higher_msb(uint32_t n);
 
+/* ---- "next" row: the caller's per-Gaussian elementwise work, fused ----
+ * gsr_activate replaces the five Torch ops of GaussianModel's getters (include/gs/gs/gaussian.cuh:40-54):
+ *   scales = exp(_scaling) [P][3], rotations = normalize(_rotation) [P][4] (x / max(|x|, 1e-12)),
+ *   opacities = sigmoid(_opacity) [P], shs = cat(_features_dc [P][1][3], _features_rest [P][M-1][3], 1).
+ * gsr_activate_backward is the matching chain rule (needs the raw rotation and the activated scales /
+ * opacities); every output element is written.
+ * gsr_adam_step is torch::optim::Adam::step (as configured in src/gs/gaussian.cu:396-428: per-group lr,
+ * no weight decay, no amsgrad) for up to 8 tensors in ONE launch; `step` counts from 1; zero_grads != 0
+ * clears the gradients it consumed (the reference's zero_grad, src/liw/lioOptimization.cpp:1831-1832).
+ * Pointer arrays are HOST arrays of device pointers. */
+int gsr_activate(int P, int M, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
+                 const float* features_dc, const float* features_rest, float* scales, float* rotations,
+                 float* opacities, float* shs, void* stream);
+int gsr_activate_backward(int P, int M, const float* rotation_raw, const float* scales, const float* opacities,
+                          const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
+                          const float* dL_dshs, float* dL_dscaling_raw, float* dL_drotation_raw,
+                          float* dL_dopacity_raw, float* dL_dfeatures_dc, float* dL_dfeatures_rest, void* stream);
+int gsr_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
+                  float* const* exp_avg_sq, const size_t* numel, const float* lr, float beta1, float beta2, float eps,
+                  int step, int zero_grads, void* stream);
+
 /* Optional per-kernel device timing (hipEvent pairs recorded on the launch stream around every
  * kernel launch while enabled).  Measurement aid for bench.py's roofline line; the reference has only
  * host wall-clock timers (include/common/timer/timer.h:36-52).  Not thread-safe; off by default.

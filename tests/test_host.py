@@ -103,10 +103,11 @@ def test_gaussian_buffer_layout():
     buf = MV.GaussianBuffer(100, 4, "cpu").load(g)
     assert buf.flat.numel() == 100 * MV.floats_per_gaussian(4) and buf.nbytes() == 100 * 23 * 4
     assert MV.floats_per_gaussian(1) * 4 == 56 and MV.floats_per_gaussian(16) * 4 == 236
+    want = dict(g, features_dc=g["shs"][:, :1], features_rest=g["shs"][:, 1:])
     for k, v in buf.views.items():
-        assert v.data_ptr() >= buf.flat.data_ptr() and np.array_equal(v.numpy(), g[k])
+        assert v.data_ptr() >= buf.flat.data_ptr() and np.array_equal(v.numpy(), want[k])
     buf.views["opacities"].fill_(0.25)
-    assert (buf.flat[100 * 10:100 * 11] == 0.25).all()
+    assert (buf.flat[100 * 22:100 * 23] == 0.25).all()
 
 
 def _free_port():
@@ -127,6 +128,7 @@ def _worker(rank, world, port, q):
             buf.load(S.make_gaussians(P, 17, sh_degree=1))
         MV.broadcast_gaussians(buf, src=0)
         want = S.make_gaussians(P, 17, sh_degree=1)
+        want.update(features_dc=want["shs"][:, :1], features_rest=want["shs"][:, 1:])
         ok = all(np.array_equal(buf.views[k].numpy(), want[k]) for k in buf.views)
         # each rank "renders" its views: gradient = (view index + 1) everywhere; owner gets the sum
         mine = MV.shard_views(5, rank, world)
