@@ -65,12 +65,14 @@ struct GeomState {
   uint32_t* block_sums;     // per 256-Gaussian block (id order): sum of tiles_touched -> exclusive offsets
   uint32_t* total;          // [1] num_rendered, device side
   uint2* slotinfo;          // {first slot of the Gaussian's instance run, x0 | y0 << 10 | rect_width << 20}
+  uint2* gpack;             // {tiles_touched, packed rect} per Gaussian: ONE 8-byte gather in depth order
   uint32_t* order;          // [P] Gaussian ids sorted by (depth bits, id); culled Gaussians last.  = dvalsA
   uint32_t* dkeysA;         // [P] depth-sort ping-pong buffers
   uint32_t* dkeysB;
   uint32_t* dvalsB;
   uint32_t* block_sums2;    // per 256-block of `order`: sum of tiles_touched -> exclusive offsets
   uint32_t* soff;           // [P+1] first instance slot of order[i] (exclusive scan in depth order); soff[P] = R
+  uint32_t* sn;             // [P] tiles_touched of order[i]
   uint32_t* srect;          // [P] packed tile rect of order[i]: x0 | y0 << 10 | width << 20
   uint32_t* sinv;           // [P] ceil(2^32 / width) of order[i] (exact division by multiply-high)
   uint8_t* touched;         // [P] 1 = the blend backward wrote at least one gradient record for this Gaussian
@@ -90,12 +92,14 @@ struct GeomState {
     g.block_sums = c.take<uint32_t>(nb + 1);
     g.total = c.take<uint32_t>(64);
     g.slotinfo = c.take<uint2>(P);
+    g.gpack = c.take<uint2>(P);
     g.order = c.take<uint32_t>(P);
     g.dkeysA = c.take<uint32_t>(P);
     g.dkeysB = c.take<uint32_t>(P);
     g.dvalsB = c.take<uint32_t>(P);
     g.block_sums2 = c.take<uint32_t>(nb + 1);
     g.soff = c.take<uint32_t>(P + 1);
+    g.sn = c.take<uint32_t>(P);
     g.srect = c.take<uint32_t>(P);
     g.sinv = c.take<uint32_t>(P);
     g.touched = c.take<uint8_t>(P);

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos, GeomState g,
     int* __restrict__ radii_out) {
   const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  uint32_t tiles = 0;
+  uint32_t tiles = 0, rect_packed = 0;
   int radius = 0;
   if (idx < fp.P) {
     const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
@@ -165,6 +165,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
         int x0, y0, x1, y1;
         tile_rect(pixx, pixy, (int)my_radius, fp.gx, fp.gy, x0, y0, x1, y1);
         const int area = (x1 - x0) * (y1 - y0);
+        rect_packed = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
         if (area != 0) {
           float rgb[3];
           uint8_t clampbits = 0;
@@ -232,6 +233,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     g.radii[idx] = radius;
     if (radii_out) radii_out[idx] = radius;
     g.tiles_touched[idx] = tiles;
+    g.gpack[idx] = make_uint2(tiles, tiles ? rect_packed : 0u);
   }
   // per-block sum of tiles_touched -> block_sums[blockIdx.x]
   __shared__ uint32_t wsum[PRE_BLOCK / 64];
@@ -295,11 +297,21 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_depth_keys(const FrameParams fp, 
   }
 }
 
-// Per 256-block of the depth-sorted order: sum of tiles_touched -> block_sums2 (scanned by k_scan_block_sums).
+// Per 256-block of the depth-sorted order: ONE 8-byte gather per Gaussian brings (tiles_touched, rect) into
+// depth order (sn, srect, sinv are then read coalesced by k_sorted_offsets / k_emit); block sums of
+// tiles_touched -> block_sums2 (scanned by k_scan_block_sums).
 __global__ __launch_bounds__(PRE_BLOCK) void k_sorted_block_sums(const FrameParams fp, GeomState g) {
   __shared__ uint32_t wsum[PRE_BLOCK / 64];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  const uint32_t n = i < fp.P ? g.tiles_touched[g.order[i]] : 0u;
+  uint32_t n = 0;
+  if (i < fp.P) {
+    const uint2 gp = g.gpack[g.order[i]];
+    n = gp.x;
+    const uint32_t rw = gp.y >> 20;
+    g.sn[i] = n;
+    g.srect[i] = gp.y;
+    g.sinv[i] = n ? 0xFFFFFFFFu / rw + 1u : 0u;  // ceil(2^32 / rw) for rw > 1 (wraps to 0 for rw == 1: k_emit)
+  }
   const uint32_t ws = wave_sum_u32(n);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
   __syncthreads();
@@ -324,8 +336,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sorted_offsets(const FrameParams 
   __shared__ uint32_t wtot[PRE_BLOCK / 64];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t id = i < fp.P ? g.order[i] : 0u;
-  const uint32_t n = i < fp.P ? g.tiles_touched[id] : 0u;
+  const uint32_t n = i < fp.P ? g.sn[i] : 0u;
   const uint32_t inc = wave_incl_scan_u32(n, lane);
   if (lane == 63) wtot[w] = inc;
   __syncthreads();
@@ -333,19 +344,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sorted_offsets(const FrameParams 
   for (int k = 0; k < w; k++) off += wtot[k];
   off += inc - n;  // exclusive
   if (i >= fp.P) return;
-  uint32_t rect = 0, inv = 0;
-  if (n) {
-    const float4 r0 = g.splats[(size_t)id * SPLAT_F4];
-    int x0, y0, x1, y1;
-    tile_rect(r0.x, r0.y, g.radii[id], fp.gx, fp.gy, x0, y0, x1, y1);
-    const uint32_t rw = (uint32_t)(x1 - x0);
-    rect = (uint32_t)x0 | ((uint32_t)y0 << 10) | (rw << 20);
-    inv = 0xFFFFFFFFu / rw + 1u;  // ceil(2^32 / rw) for rw > 1 (wraps to 0 for rw == 1, handled in k_emit)
-    g.slotinfo[id] = make_uint2(off, rect);
-  }
   g.soff[i] = off;
-  g.srect[i] = rect;
-  g.sinv[i] = inv;
+  if (n) g.slotinfo[g.order[i]] = make_uint2(off, g.srect[i]);
   if (i == fp.P - 1) g.soff[fp.P] = off + n;
 }
 
