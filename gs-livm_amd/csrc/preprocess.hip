@@ -387,27 +387,60 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
   __syncthreads();
   const int i0 = s_range[0];
   const int S = s_range[1] - i0 + 1;  // <= EMIT_CHUNK + 1: every visible Gaussian owns >= 1 slot
-  for (int j = tid; j < S; j += 256) {
+  for (int j = tid; j <= S; j += 256) {  // s_off[S] = start of the first run beyond this chunk (soff has P+1 entries)
     s_off[j] = g.soff[i0 + j];
-    s_id[j] = g.order[i0 + j];
-    s_rect[j] = g.srect[i0 + j];
-    s_inv[j] = g.sinv[i0 + j];
+    if (j < S) {
+      s_id[j] = g.order[i0 + j];
+      s_rect[j] = g.srect[i0 + j];
+      s_inv[j] = g.sinv[i0 + j];
+    }
   }
   __syncthreads();
-  for (uint32_t t = c0 + tid; t < c1; t += 256) {
-    int lo = 0, hi = S - 1;  // largest j with s_off[j] <= t
+  // Each thread owns EIGHT consecutive slots: one bisection for the first, then it walks (row, col) and steps to
+  // the next Gaussian when a run ends -- 4x fewer LDS round trips than a search per slot, 32-byte stores.
+  const uint32_t t0 = c0 + (uint32_t)tid * 8u;
+  if (t0 >= c1) return;
+  int j = 0;
+  {
+    int lo = 0, hi = S - 1;  // largest j with s_off[j] <= t0
     while (lo < hi) {
       const int mid = (lo + hi + 1) >> 1;
-      if (s_off[mid] <= t) lo = mid; else hi = mid - 1;
+      if (s_off[mid] <= t0) lo = mid; else hi = mid - 1;
     }
-    const uint32_t rc = s_rect[lo];
-    const uint32_t rw = rc >> 20;
-    const uint32_t local = t - s_off[lo];
-    // local < 2^20, rw < 2^10  =>  local * (inv*rw - 2^32) < 2^32: the multiply-high quotient is exact
-    const uint32_t row = rw == 1u ? local : __umulhi(local, s_inv[lo]);
-    const uint32_t col = local - row * rw;
-    tkeys_out[t] = (((rc >> 10) & 1023u) + row) * (uint32_t)fp.gx + (rc & 1023u) + col;
-    ivals_out[t] = s_id[lo];
+    j = lo;
+  }
+  uint32_t rc = s_rect[j], rw = rc >> 20, id = s_id[j], next = s_off[j + 1];
+  uint32_t local = t0 - s_off[j];
+  // local < 2^20, rw < 2^10  =>  local * (inv*rw - 2^32) < 2^32: the multiply-high quotient is exact
+  uint32_t row = rw == 1u ? local : __umulhi(local, s_inv[j]);
+  uint32_t col = local - row * rw;
+  uint32_t tk[8], iv[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    tk[k] = (((rc >> 10) & 1023u) + row) * (uint32_t)fp.gx + (rc & 1023u) + col;
+    iv[k] = id;
+    const uint32_t t = t0 + (uint32_t)k + 1u;
+    if (t == next && t < c1) {  // run finished: next Gaussian (every staged Gaussian owns >= 1 slot)
+      j++;
+      rc = s_rect[j]; rw = rc >> 20; id = s_id[j]; next = s_off[j + 1];
+      row = 0; col = 0;
+    } else if (++col == rw) {
+      col = 0;
+      row++;
+    }
+  }
+  if (t0 + 8u <= c1) {
+    uint4* ko = reinterpret_cast<uint4*>(tkeys_out + t0);
+    uint4* vo = reinterpret_cast<uint4*>(ivals_out + t0);
+    ko[0] = make_uint4(tk[0], tk[1], tk[2], tk[3]);
+    ko[1] = make_uint4(tk[4], tk[5], tk[6], tk[7]);
+    vo[0] = make_uint4(iv[0], iv[1], iv[2], iv[3]);
+    vo[1] = make_uint4(iv[4], iv[5], iv[6], iv[7]);
+  } else {
+    for (int k = 0; k < 8 && t0 + (uint32_t)k < c1; k++) {
+      tkeys_out[t0 + k] = tk[k];
+      ivals_out[t0 + k] = iv[k];
+    }
   }
 }
 

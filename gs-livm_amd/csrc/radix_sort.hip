@@ -59,32 +59,29 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, int lane, in
   return o + inc - v;
 }
 
+// Per-tile digit counts with LDS integer atomics (order-independent, so still deterministic): three
+// instructions per key instead of a ballot match; neighbouring keys rarely share a digit in either sort.
 __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ keys, int n, int shift, int nbits,
                                                    uint32_t* __restrict__ counts) {
-  __shared__ uint32_t hist[4][256];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __shared__ uint32_t hist[256];
+  const int tid = threadIdx.x;
   const uint32_t mask = (1u << nbits) - 1u;
+  hist[tid] = 0;
+  __syncthreads();
+  const size_t base = (size_t)blockIdx.x * SORT_TILE;
+  uint32_t key[SORT_TILE / 256];
 #pragma unroll
-  for (int k = 0; k < 4; k++) hist[w][lane + 64 * k] = 0;
-  const size_t base = (size_t)blockIdx.x * SORT_TILE + (size_t)w * WAVE_TILE;
-  uint32_t key[STEPS];
-#pragma unroll
-  for (int s = 0; s < STEPS; s++) {
-    const size_t i = base + (size_t)s * 64 + lane;
-    key[s] = i < (size_t)n ? keys[i] : 0u;
+  for (int s = 0; s < SORT_TILE / 256; s++) {
+    const size_t i = base + (size_t)s * 256 + tid;
+    key[s] = i < (size_t)n ? keys[i] : 0xFFFFFFFFu;
   }
 #pragma unroll
-  for (int s = 0; s < STEPS; s++) {
-    const size_t i = base + (size_t)s * 64 + lane;
-    const bool valid = i < (size_t)n;
-    const uint32_t d = (key[s] >> shift) & mask;
-    const uint64_t m = match_digit(d, valid, nbits);
-    const int rank = __popcll(m & lanemask_lt(lane));
-    if (valid && rank == 0) hist[w][d] += (uint32_t)__popcll(m);  // one leader per digit: no conflicts
+  for (int s = 0; s < SORT_TILE / 256; s++) {
+    const size_t i = base + (size_t)s * 256 + tid;
+    if (i < (size_t)n) atomicAdd(&hist[(key[s] >> shift) & mask], 1u);
   }
   __syncthreads();
-  const int d = threadIdx.x;
-  counts[(size_t)blockIdx.x * 256 + d] = hist[0][d] + hist[1][d] + hist[2][d] + hist[3][d];
+  counts[(size_t)blockIdx.x * 256 + tid] = hist[tid];
 }
 
 // grid = nchunks, block = 256 (thread = digit).
