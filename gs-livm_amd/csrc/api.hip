@@ -56,7 +56,7 @@ void prof_end(hipStream_t s) {
 }
 }  // namespace gsr
 static const char* const kKernelNames[K_COUNT] = {
-    "k_preprocess", "k_scan_block_sums", "k_depth_keys", "k_sorted_block_sums", "k_sorted_offsets", "k_emit",
+    "k_preprocess", "k_scan_block_sums", "k_depth_keys", "k_sorted_block_sums", "k_sorted_offsets", "k_emit_chunks", "k_emit",
     "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top", "k_sort_scatter", "k_tile_ranges", "k_blend_forward",
     "k_blend_backward", "k_compact_touched", "k_gather_records", "k_gaussian_backward", "k_mark_visible", "k_sort_hist[depth]",
     "k_sort_scan_chunks[depth]", "k_sort_scan_top[depth]", "k_sort_scatter[depth]", "k_activate",
@@ -201,7 +201,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const int tiles = fp.gx * fp.gy;
   const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
   const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
-  STAGE(launch_emit(fp, g, R, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB, stream));
+  STAGE(launch_emit(fp, g, R, b.chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB,
+                    stream));
   STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, R, tile_bits, start_in_A,
                           /*is_depth_sort=*/false, stream));
   STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, tiles, stream));

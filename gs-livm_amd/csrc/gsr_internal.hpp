@@ -146,6 +146,7 @@ struct BinningState {
   SortScratch tsort;
   float4* grad_inst;     // [R][3], aliases tkeysA..tsort
   uint8_t* inst_flag;    // [R] 1 = grad_inst[slot] was written by the blend backward
+  uint32_t* chunk_first; // [R/EMIT_CHUNK + 2] depth-order index of the Gaussian covering slot k*EMIT_CHUNK
   static BinningState carve(char* blob, size_t R, size_t* bytes = nullptr) {
     Carver c(blob);
     BinningState b;
@@ -161,6 +162,7 @@ struct BinningState {
     b.grad_inst = g.take<float4>(R * GRAD_F4);
     c.off = sort_end > g.off ? sort_end : g.off;
     b.inst_flag = c.take<uint8_t>(R);
+    b.chunk_first = c.take<uint32_t>(R / EMIT_CHUNK + 2);
     if (bytes) *bytes = align_up(c.off) + ALIGN;
     return b;
   }
@@ -180,8 +182,8 @@ hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, hipSt
 hipError_t launch_depth_keys(const FrameParams& fp, GeomState g, uint32_t* keys_out, uint32_t* vals_out, hipStream_t s);
 hipError_t launch_sorted_block_sums(const FrameParams& fp, GeomState g, hipStream_t s);
 hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
-hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* tkeys_out, uint32_t* ivals_out,
-                       hipStream_t s);
+hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
+                       uint32_t* ivals_out, hipStream_t s);
 hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningState b, float* dL_dmean2D,
                                  float* dL_dconic, float* dL_dopacity, float* dL_dcolor, hipStream_t s);
 // Stable LSD radix sort of n (u32, u32) pairs on key bits [0, end_bit); buffers ping-pong between
@@ -219,7 +221,7 @@ inline int sort_digit_bits(int end_bit) { const int p = sort_passes(end_bit); re
 
 // Kernel ids for the optional event profiler (api.hip); order = gsr_kernel_name().
 enum KernelId {
-  K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DEPTH_KEYS, K_SORTED_SUMS, K_SORTED_OFFSETS, K_EMIT, K_SORT_HIST,
+  K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DEPTH_KEYS, K_SORTED_SUMS, K_SORTED_OFFSETS, K_EMIT_CHUNKS, K_EMIT, K_SORT_HIST,
   K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_COMPACT_TOUCHED,
   K_GATHER_RECORDS, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_DSORT_HIST, K_DSORT_SCAN_CHUNKS, K_DSORT_SCAN_TOP,
   K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_COUNT

@@ -349,44 +349,34 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sorted_offsets(const FrameParams 
   if (i == fp.P - 1) g.soff[fp.P] = off + n;
 }
 
-// Number of elements of the sorted array a[0..n) that are <= key (inclusive) or < key; whole wave cooperates.
-__device__ __forceinline__ int wave_count_below(const uint32_t* __restrict__ a, int n, uint32_t key, bool inclusive,
-                                                int lane) {
-  int lo = 0, hi = n;  // a[0..lo) satisfy the predicate, a[hi..n) do not
-  while (hi - lo > 64) {
-    const int step = (hi - lo + 63) / 64;
-    const int idx = lo + lane * step;
-    const bool in = idx < hi;
-    const uint32_t v = in ? a[idx] : 0xFFFFFFFFu;
-    const bool sat = in && (inclusive ? v <= key : v < key);
-    const int cnt = __popcll(__ballot(sat));  // probes are sorted: the satisfying ones are a prefix
-    if (cnt == 0) { hi = lo; break; }
-    const int nlo = lo + (cnt - 1) * step;  // a[nlo] satisfies
-    const int nhi = nlo + step < hi ? nlo + step : hi;
-    lo = nlo + 1;
-    hi = nhi;
-  }
-  const int idx = lo + lane;
-  const bool sat = idx < hi && (inclusive ? a[idx] <= key : a[idx] < key);
-  return lo + __popcll(__ballot(sat));
+// For every chunk boundary k*EMIT_CHUNK, the depth-order index of the Gaussian whose run covers that slot
+// (each Gaussian writes the boundaries inside its own run: usually none or one, dozens for the nearest
+// Gaussians).  chunk_first[nchunks] = the last Gaussian that owns any slot.  Saves k_emit two dependent
+// multi-step searches per workgroup.
+__global__ __launch_bounds__(PRE_BLOCK) void k_emit_chunks(const FrameParams fp, GeomState g, const int R,
+                                                           uint32_t* __restrict__ chunk_first) {
+  const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  if (i >= fp.P) return;
+  const uint32_t n = g.sn[i];
+  if (!n) return;
+  const uint32_t off = g.soff[i], end = off + n;
+  for (uint32_t k = (off + EMIT_CHUNK - 1) / EMIT_CHUNK; (unsigned long long)k * EMIT_CHUNK < end; k++)
+    chunk_first[k] = (uint32_t)i;
+  if (end == (uint32_t)R) chunk_first[(R + EMIT_CHUNK - 1) / EMIT_CHUNK] = (uint32_t)i;
 }
 
 __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g, const int R,
+                                              const uint32_t* __restrict__ chunk_first,
                                               uint32_t* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out) {
   __shared__ uint32_t s_off[EMIT_CHUNK + 2], s_id[EMIT_CHUNK + 1], s_rect[EMIT_CHUNK + 1], s_inv[EMIT_CHUNK + 1];
-  __shared__ int s_range[2];
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tid = threadIdx.x;
   const uint32_t c0 = (uint32_t)blockIdx.x * EMIT_CHUNK;
   const uint32_t c1 = c0 + EMIT_CHUNK < (uint32_t)R ? c0 + EMIT_CHUNK : (uint32_t)R;
-  if (w == 0) {
-    // i0 = last Gaussian whose run starts at or before c0; i1 = last Gaussian whose run starts before c1
-    const int i0 = wave_count_below(g.soff, fp.P + 1, c0, true, lane) - 1;
-    const int i1 = wave_count_below(g.soff, fp.P + 1, c1, false, lane) - 1;
-    if (lane == 0) { s_range[0] = i0; s_range[1] = i1; }
-  }
-  __syncthreads();
-  const int i0 = s_range[0];
-  const int S = s_range[1] - i0 + 1;  // <= EMIT_CHUNK + 1: every visible Gaussian owns >= 1 slot
+  // i0 = Gaussian covering slot c0; i1 = last Gaussian whose run starts before c1
+  const int i0 = (int)chunk_first[blockIdx.x];
+  int i1 = (int)chunk_first[blockIdx.x + 1];
+  if (c1 < (uint32_t)R && g.soff[i1] >= c1) i1--;  // the Gaussian covering slot c1 starts exactly there
+  const int S = i1 - i0 + 1;  // <= EMIT_CHUNK + 1: every visible Gaussian owns >= 1 slot
   for (int j = tid; j <= S; j += 256) {  // s_off[S] = start of the first run beyond this chunk (soff has P+1 entries)
     s_off[j] = g.soff[i0 + j];
     if (j < S) {
@@ -812,11 +802,17 @@ hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, hipStream_t
   return hipGetLastError();
 }
 
-hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* tkeys_out, uint32_t* ivals_out,
-                       hipStream_t s) {
+hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
+                       uint32_t* ivals_out, hipStream_t s) {
   if (R <= 0) return hipSuccess;
+  {
+    ProfScope ps(K_EMIT_CHUNKS, s);
+    hipLaunchKernelGGL(k_emit_chunks, dim3((fp.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s, fp, g, R,
+                       chunk_first);
+  }
   ProfScope ps(K_EMIT, s);
-  hipLaunchKernelGGL(k_emit, dim3((R + EMIT_CHUNK - 1) / EMIT_CHUNK), dim3(256), 0, s, fp, g, R, tkeys_out, ivals_out);
+  hipLaunchKernelGGL(k_emit, dim3((R + EMIT_CHUNK - 1) / EMIT_CHUNK), dim3(256), 0, s, fp, g, R, chunk_first,
+                     tkeys_out, ivals_out);
   return hipGetLastError();
 }
 

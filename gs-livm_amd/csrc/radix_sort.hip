@@ -18,7 +18,10 @@
 //                      popcount of lower lanes, per-wave running counts live in LDS; the tile is then
 //                      REORDERED IN LDS by digit and written out run by run, so global stores are
 //                      coalesced runs instead of 64 scattered dwords per instruction.
-// Every step is order-preserving (stable); no atomics, no inter-workgroup communication.
+// Every step is order-preserving (stable); no float atomics, no inter-workgroup communication inside a launch.
+// (A single-pass decoupled-look-back variant -- tile tickets, per-digit status words, sc1 relaxed loads -- was
+// built and measured in round 1: correct, but 0.66 ms vs 0.51 ms for the tile sort at C3, so it was dropped;
+// see DESIGN.md "Tried and rejected".)
 #include "gsr_internal.hpp"
 
 namespace gsr {
