@@ -52,6 +52,7 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
         "k_sort_scan_chunks[depth]": (P // 4096 + 1) * 2048, "k_sort_scan_top[depth]": 0,
         "k_sorted_block_sums": P * 8,
         "k_sorted_offsets": P * 8 + P_vis * 20 + P * 12 + P_vis * 8,
+        "k_emit_chunks": P * 8,
         "k_emit": R * 8 + P_vis * 16,
         "k_sort_hist": R * 4, "k_sort_scatter": R * 16,           # (u32 tile, u32 id): read 8 B + write 8 B per pass
         "k_sort_scan_chunks": (R // 4096 + 1) * 2048, "k_sort_scan_top": 0,
@@ -61,6 +62,10 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
         "k_compact_touched": P * 1 + P_vis * 0,
         "k_gather_records": R_bwd * 48,
         "k_gaussian_backward": P * (108 + 12 * M) + P_vis * (111 + 12 * M) + P_vis * (64 + 12 * M),
+        # "next" row kernels: activations read/write the 14 + 3(M-1)... floats per Gaussian once each way
+        "k_activate": P * 4 * (11 + 3 * M) * 2 - P * 24,          # xyz is not touched
+        "k_activate_backward": P * 4 * (8 + 3 * M) * 2 + P * 4 * 8,
+        "k_adam": P * 4 * (11 + 3 * M) * 7,                       # p, g, m, v read; p, m, v (+ zeroed g) written
     }
 
 
@@ -202,7 +207,7 @@ def main():
         P_vis = int((radii > 0).sum())
         v = G.state_views(fw[5], fw[6], fw[7], P, R, W, H)
         ln = (v["ranges"][:, 1] - v["ranges"][:, 0]).float()
-        R_bwd = int(v["tile_last"].long().sum())
+        R_bwd = int(v["quad_last"].long().max(1).values.sum())
         stats = dict(P=P, P_vis=P_vis, R=R, R_walked_by_backward=R_bwd, tiles=int(ln.numel()),
                      mean_tile_list=float(ln.mean()), max_tile_list=int(ln.max()),
                      mean_contrib_per_pixel=float(v["n_contrib"].float().mean()))
@@ -215,7 +220,7 @@ def main():
             kernels[name] = dict(ms_per_step=ms / args.steps, launches_per_step=cnt / args.steps,
                                  avg_launch_ms=ms / cnt,
                                  alg_GBps=(alg.get(name, 0) / (ms / cnt * 1e-3) / 1e9) if ms > 0 else None)
-    dom = max(kernels, key=lambda k: kernels[k]["ms_per_step"])
+    dom = max((k for k in kernels if alg.get(k)), key=lambda k: kernels[k]["ms_per_step"])
     achieved = alg[dom] / (kernels[dom]["avg_launch_ms"] * 1e-3) / 1e9
     # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3
     # passes, corrected as tools/pmc_summary.py documents): PMC collection cannot run inside a timed bench, so the

@@ -26,7 +26,7 @@ class BinningView(C.Structure):
 
 
 class ImageView(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("ranges", "final_T", "n_contrib", "tile_last")]
+    _fields_ = [(n, C.c_void_p) for n in ("ranges", "final_T", "n_contrib", "quad_last")]
 
 
 _lib = None
@@ -226,7 +226,7 @@ def state_views(geomBuffer, binningBuffer, imageBuffer, P, R, W, H):
         out.update(ranges=_sub(imageBuffer, iv.ranges, T * 2, torch.int32).view(T, 2),
                    final_T=_sub(imageBuffer, iv.final_T, W * H, torch.float32).view(H, W),
                    n_contrib=_sub(imageBuffer, iv.n_contrib, W * H, torch.int32).view(H, W),
-                   tile_last=_sub(imageBuffer, iv.tile_last, T, torch.int32))
+                   quad_last=_sub(imageBuffer, iv.quad_last, T * 4, torch.int32).view(T, 4))
         if R:
             _check(L.gsr_binning_view_of(_ptr(binningBuffer), R, C.byref(bv)))
             tile_ids = _sub(binningBuffer, bv.tile_ids, R, torch.int32)

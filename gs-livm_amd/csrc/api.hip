@@ -334,7 +334,7 @@ int gsr_image_view_of(char* image_buffer, int width, int height, gsr_image_view*
   out->ranges = reinterpret_cast<const uint32_t*>(im.ranges);
   out->final_T = im.final_T;
   out->n_contrib = im.n_contrib;
-  out->tile_last = im.tile_last;
+  out->quad_last = im.quad_last;
   return GSR_OK;
 }
 

@@ -113,7 +113,7 @@ struct GeomState {
 // Per-image state (replaces ImageState, rasterizer_impl.cu:153-159).
 struct ImageState {
   uint2* ranges;        // [tiles]
-  uint32_t* tile_last;  // [tiles] max n_contrib over the tile's pixels (bounds the backward walk)
+  uint32_t* quad_last;  // [tiles][4] max n_contrib over each 8x8 quad's pixels (bounds the backward walk)
   float* final_T;       // [H*W]
   uint32_t* n_contrib;  // [H*W]
   static ImageState carve(char* blob, int W, int H, size_t* bytes = nullptr) {
@@ -122,7 +122,7 @@ struct ImageState {
     size_t tiles = (size_t)((W + TILE - 1) / TILE) * ((H + TILE - 1) / TILE);
     size_t N = (size_t)W * H;
     s.ranges = c.take<uint2>(tiles);
-    s.tile_last = c.take<uint32_t>(tiles);
+    s.quad_last = c.take<uint32_t>(tiles * 4);
     s.final_T = c.take<float>(N);
     s.n_contrib = c.take<uint32_t>(N);
     if (bytes) *bytes = align_up(c.off) + ALIGN;

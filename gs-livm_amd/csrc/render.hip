@@ -24,7 +24,7 @@
 
 namespace gsr {
 
-constexpr int CHUNK = 256;
+
 
 template <int CTRL, int ROW_MASK, int BANK_MASK>
 __device__ __forceinline__ float dpp_get(float v) {
@@ -110,92 +110,96 @@ __device__ __forceinline__ uint32_t quad_hits(float x, float y, float hx, float 
 }
 
 // ------------------------------------------------------------------------------------------------
-// F8 forward blend.
+// F8 forward blend.  ONE WAVE PER 8x8 QUAD, no workgroup barriers at all: the four quads of a tile are four
+// independent 64-thread workgroups (consecutive block ids, so they share the tile's splats in L2).  A wave
+// streams the tile's list in sub-chunks of 64 -- each lane gathers one 48-B record (the next sub-chunk's gather
+// is issued before the current one is consumed), the footprint-box test against ITS quad and one ballot give
+// the hit mask, records go to a 3-KB wave-private LDS image and are read back by broadcast -- and stops the
+// moment its 64 pixels are saturated.  The redundant gathers (each record is fetched by up to four waves) hit
+// L2; in exchange no wave ever waits for a slower quad, which the SQ counters showed to be the dominant cost
+// of a barrier-per-chunk design (VALU active 14 % of wave cycles).
+// quad_last[4*tile + q] = max n_contrib inside the quad: bounds the backward walk.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_blend_forward(const FrameParams fp, const uint2* __restrict__ ranges,
-                                                       const uint32_t* __restrict__ point_list,
-                                                       const float4* __restrict__ splats,
-                                                       const float* __restrict__ bg, float* __restrict__ final_T,
-                                                       uint32_t* __restrict__ n_contrib,
-                                                       uint32_t* __restrict__ tile_last, float* __restrict__ out_color,
-                                                       float* __restrict__ out_depth, float* __restrict__ out_acc) {
-  __shared__ float4 sA[CHUNK], sB[CHUNK], sC[CHUNK];
-  __shared__ uint64_t smask[4][4];  // [quad][loader wave]
-  __shared__ uint32_t s_last;
-  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int tile = blockIdx.y * fp.gx + blockIdx.x;
-  const int px = blockIdx.x * TILE + (w & 1) * 8 + (lane & 7);
-  const int py = blockIdx.y * TILE + (w >> 1) * 8 + (lane >> 3);
+__global__ __launch_bounds__(64) void k_blend_forward(const FrameParams fp, const uint2* __restrict__ ranges,
+                                                      const uint32_t* __restrict__ point_list,
+                                                      const float4* __restrict__ splats,
+                                                      const float* __restrict__ bg, float* __restrict__ final_T,
+                                                      uint32_t* __restrict__ n_contrib,
+                                                      uint32_t* __restrict__ quad_last, float* __restrict__ out_color,
+                                                      float* __restrict__ out_depth, float* __restrict__ out_acc) {
+  __shared__ float4 sA[64], sB[64], sC[64];
+  const int lane = threadIdx.x;
+  const int tile = blockIdx.x >> 2, q = blockIdx.x & 3;
+  const int tile_x = tile % fp.gx, tile_y = tile / fp.gx;
+  const int qx = tile_x * TILE + (q & 1) * 8, qy = tile_y * TILE + (q >> 1) * 8;
+  const int px = qx + (lane & 7), py = qy + (lane >> 3);
   const bool inside = px < fp.W && py < fp.H;
   const float pfx = (float)px, pfy = (float)py;
-  const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
+  const float qx0 = (float)qx, qy0 = (float)qy;
   const uint2 range = ranges[tile];
   const int n = (int)(range.y - range.x);
-  if (tid == 0) s_last = 0;
 
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, A = 0.f;
   uint32_t last = 0;
   bool done = !inside;
   bool wave_done = __ballot(!done) == 0ull;
 
-  for (int base = 0; base < n; base += CHUNK) {
-    const int j = base + tid;
-    uint32_t hits = 0;
-    if (j < n) {
-      const uint32_t id = point_list[range.x + j];
-      const float4 a = splats[(size_t)id * SPLAT_F4 + 0];
-      const float4 b = splats[(size_t)id * SPLAT_F4 + 1];
-      const float4 c = splats[(size_t)id * SPLAT_F4 + 2];
-      sA[tid] = a;
-      sB[tid] = b;
-      sC[tid] = c;
-      hits = quad_hits(a.x, a.y, c.z, c.w, tx0, ty0);
+  // software pipeline: (a, b, c, hit) hold the sub-chunk about to be consumed
+  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+  bool hit = false;
+  if (!wave_done && lane < n) {
+    const uint32_t id = point_list[range.x + lane];
+    a = splats[(size_t)id * SPLAT_F4 + 0];
+    b = splats[(size_t)id * SPLAT_F4 + 1];
+    c = splats[(size_t)id * SPLAT_F4 + 2];
+    hit = (a.x + c.z >= qx0) && (a.x - c.z <= qx0 + 7.0f) && (a.y + c.w >= qy0) && (a.y - c.w <= qy0 + 7.0f);
+  }
+  for (int base = 0; base < n && !wave_done; base += 64) {
+    sA[lane] = a;
+    sB[lane] = b;
+    sC[lane] = c;
+    uint64_t m = __ballot(hit);
+    // issue the next sub-chunk's gather now; it completes while this one is blended
+    const int jn = base + 64 + lane;
+    hit = false;
+    if (jn < n) {
+      const uint32_t id = point_list[range.x + jn];
+      a = splats[(size_t)id * SPLAT_F4 + 0];
+      b = splats[(size_t)id * SPLAT_F4 + 1];
+      c = splats[(size_t)id * SPLAT_F4 + 2];
+      hit = (a.x + c.z >= qx0) && (a.x - c.z <= qx0 + 7.0f) && (a.y + c.w >= qy0) && (a.y - c.w <= qy0 + 7.0f);
     }
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint64_t m = __ballot((hits >> q) & 1u);
-      if (lane == 0) smask[q][w] = m;
-    }
-    __syncthreads();
-    if (!wave_done) {
-      for (int lw = 0; lw < 4 && !wave_done; lw++) {
-        uint64_t m = uniform_u64(smask[w][lw]);
-        while (m) {
-          const int bpos = __builtin_ctzll(m);
-          m &= m - 1;
-          const int jj = lw * 64 + bpos;
-          const float4 a = sA[jj];
-          const float4 b = sB[jj];
-          const float4 c = sC[jj];
-          const float dx = a.x - pfx, dy = a.y - pfy;
-          const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-          const float alpha = fminf(0.99f, b.y * __expf(power));
-          bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-          const float test_T = T * (1.0f - alpha);
-          const bool stop = ok && (test_T < 0.0001f);
-          done = done || stop;
-          ok = ok && !stop;
-          const float wgt = ok ? alpha * T : 0.0f;
-          C0 += b.z * wgt;
-          C1 += b.w * wgt;
-          C2 += c.x * wgt;
-          Dp += c.y * wgt;
-          A += wgt;
-          T = ok ? test_T : T;
-          last = ok ? (uint32_t)(base + jj + 1) : last;
-          if (__ballot(!done) == 0ull) {
-            wave_done = true;
-            break;
-          }
-        }
+    while (m) {
+      const int jj = __builtin_ctzll(m);
+      m &= m - 1;
+      const float4 ra = sA[jj];
+      const float4 rb = sB[jj];
+      const float4 rc = sC[jj];
+      const float dx = ra.x - pfx, dy = ra.y - pfy;
+      const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
+      const float alpha = fminf(0.99f, rb.y * __expf(power));
+      bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+      const float test_T = T * (1.0f - alpha);
+      const bool stop = ok && (test_T < 0.0001f);
+      done = done || stop;
+      ok = ok && !stop;
+      const float wgt = ok ? alpha * T : 0.0f;
+      C0 += rb.z * wgt;
+      C1 += rb.w * wgt;
+      C2 += rc.x * wgt;
+      Dp += rc.y * wgt;
+      A += wgt;
+      T = ok ? test_T : T;
+      last = ok ? (uint32_t)(base + jj + 1) : last;
+      if (__ballot(!done) == 0ull) {
+        wave_done = true;
+        break;
       }
     }
-    if (__syncthreads_and(wave_done)) break;
   }
-  __syncthreads();  // s_last initialised (covers the n == 0 case, where the loop has no barrier)
 
   const uint32_t wl = wave_max_u32(inside ? last : 0u);
-  if (lane == 0) atomicMax(&s_last, wl);
+  if (lane == 0) quad_last[blockIdx.x] = wl;
   if (inside) {
     const size_t pid = (size_t)fp.W * py + px;
     const size_t N = (size_t)fp.W * fp.H;
@@ -207,27 +211,32 @@ __global__ __launch_bounds__(256) void k_blend_forward(const FrameParams fp, con
     out_depth[pid] = Dp;
     out_acc[pid] = A;
   }
-  __syncthreads();
-  if (tid == 0) tile_last[tile] = s_last;
 }
 
 // ------------------------------------------------------------------------------------------------
 // B1 backward blend.
 // ------------------------------------------------------------------------------------------------
+// BCHUNK = list entries staged per round (one per thread of the first BCHUNK/64 waves).  128 instead of 256
+// halves the LDS footprint (the per-quad partial sums dominate it), doubling the resident workgroups per CU:
+// the kernel is latency-bound at 3 waves/SIMD (SQ counters: VALU issue active 36 % of wave cycles).
+template <int BCHUNK>
 __global__ __launch_bounds__(256) void k_blend_backward(
-    const FrameParams fp, const uint2* __restrict__ ranges, const uint32_t* __restrict__ tile_last,
+    const FrameParams fp, const uint2* __restrict__ ranges, const uint32_t* __restrict__ quad_last_in,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const uint2* __restrict__ slotinfo,
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dacc, float4* __restrict__ grad_inst,
     uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched) {
-  __shared__ float4 sA[CHUNK], sB[CHUNK];
-  __shared__ float sBlue[CHUNK];
-  __shared__ uint32_t sSlot[CHUNK], sId[CHUNK];
-  __shared__ uint64_t smask[4][4];
-  __shared__ __attribute__((aligned(8))) float sPart[4][CHUNK][10];  // 9 used; 8-B aligned pairs
+  constexpr int LW = BCHUNK / 64;  // loader waves
+  __shared__ float4 sA[BCHUNK], sB[BCHUNK];
+  __shared__ float sBlue[BCHUNK];
+  __shared__ uint32_t sSlot[BCHUNK], sId[BCHUNK];
+  __shared__ uint64_t smask[4][LW];
+  __shared__ __attribute__((aligned(8))) float sPart[4][BCHUNK][10];  // 9 used; 8-B aligned pairs
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tile = blockIdx.y * fp.gx + blockIdx.x;
-  const int n = (int)tile_last[tile];  // entries [0, n) of the tile's list can carry gradient
+  const uint32_t ql0 = quad_last_in[4 * tile], ql1 = quad_last_in[4 * tile + 1], ql2 = quad_last_in[4 * tile + 2],
+                 ql3 = quad_last_in[4 * tile + 3];
+  const int n = (int)max(max(ql0, ql1), max(ql2, ql3));  // entries [0, n) of the tile's list can carry gradient
   if (n == 0) return;
   const uint32_t rbase = ranges[tile].x;
   const int px = blockIdx.x * TILE + (w & 1) * 8 + (lane & 7);
@@ -248,12 +257,13 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, aacc = 0.f;  // accum_rec, accum_acc_rec
   float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_acc = 0.f;
   // entries at or beyond the quad's own last contributor cannot receive gradient from this wave
-  const int quad_last = (int)__builtin_amdgcn_readfirstlane(wave_max_u32((uint32_t)lastc));
+  const int quad_last = (int)(w == 0 ? ql0 : w == 1 ? ql1 : w == 2 ? ql2 : ql3);
 
-  for (int base = 0; base < n; base += CHUNK) {
+  for (int base = 0; base < n; base += BCHUNK) {
     const int k = base + tid;  // k-th entry counted from the back of [0, n)
+    const bool stager = tid < BCHUNK;
     uint32_t hits = 0;
-    if (k < n) {
+    if (stager && k < n) {
       const int pos = n - 1 - k;
       const uint32_t id = point_list[rbase + pos];
       const float4 a = splats[(size_t)id * SPLAT_F4 + 0];
@@ -268,13 +278,15 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       sSlot[tid] = si.x + (uint32_t)(((int)blockIdx.y - y0) * rw + ((int)blockIdx.x - x0));
       hits = quad_hits(a.x, a.y, c.z, c.w, tx0, ty0);
     }
+    if (w < LW) {
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const uint64_t m = __ballot((hits >> q) & 1u);
-      if (lane == 0) smask[q][w] = m;
+      for (int q = 0; q < 4; q++) {
+        const uint64_t m = __ballot((hits >> q) & 1u);
+        if (lane == 0) smask[q][w] = m;
+      }
     }
     __syncthreads();
-    for (int lw = 0; lw < 4; lw++) {
+    for (int lw = 0; lw < LW; lw++) {
       uint64_t m = uniform_u64(smask[w][lw]);
       while (m) {
         const int bpos = __builtin_ctzll(m);
@@ -343,7 +355,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       }
     }
     __syncthreads();
-    if (k < n) {
+    if (stager && k < n) {
       // hit bits of entry `tid`, quad order 0..3 fixed => reproducible sums
       const int lw = tid >> 6;
       float s[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -374,15 +386,15 @@ __global__ __launch_bounds__(256) void k_blend_backward(
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, hipStream_t s) {
   ProfScope ps_k_blend_fwd(K_BLEND_FWD, s);
-  hipLaunchKernelGGL(k_blend_forward, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, b.point_list, g.splats, bg,
-                     im.final_T, im.n_contrib, im.tile_last, out_color, out_depth, out_acc);
+  hipLaunchKernelGGL(k_blend_forward, dim3(fp.gx * fp.gy * 4), dim3(64), 0, s, fp, im.ranges, b.point_list, g.splats,
+                     bg, im.final_T, im.n_contrib, im.quad_last, out_color, out_depth, out_acc);
   return hipGetLastError();
 }
 
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                  const float* dL_dpix, const float* dL_dacc, hipStream_t s) {
   ProfScope ps_k_blend_bwd(K_BLEND_BWD, s);
-  hipLaunchKernelGGL(k_blend_backward, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, im.tile_last, b.point_list,
+  hipLaunchKernelGGL(k_blend_backward<128>, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, im.quad_last, b.point_list,
                      g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst, b.inst_flag,
                      g.touched);
   return hipGetLastError();

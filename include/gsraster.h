@@ -118,7 +118,8 @@ typedef struct gsr_image_view {
   const uint32_t* ranges;         /* [tiles][2]                           */
   const float* final_T;           /* [H][W]                               */
   const uint32_t* n_contrib;      /* [H][W]                               */
-  const uint32_t* tile_last;      /* [tiles] max n_contrib inside the tile = list entries the backward walks */
+  const uint32_t* quad_last;      /* [tiles][4] max n_contrib inside each 8x8 quad of the tile (0,1 = top, 2,3 = bottom);
+                                     the tile's maximum = list entries the backward walks */
 } gsr_image_view;
 int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out);
 int gsr_binning_view_of(char* binning_buffer, int R, gsr_binning_view* out);
