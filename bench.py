@@ -12,10 +12,11 @@ reference's groups / learning rates.  Activations and Adam run as the fused HIP 
 (SURVEY.md 8(f) "next" row 1) unless --torch-optimizer selects the reference's separate Torch ops.
 Inputs are resident in HBM before the timed region.  value = Mpixels/s of the whole job.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): rank r renders view r of the same scene
-(yaw offsets of SURVEY.md 8(d)); per step the optimiser owner (rank 0) broadcasts the flat parameter buffer,
-every rank renders forward + backward, the per-view gradients are reduced onto rank 0, rank 0 steps Adam
-(SURVEY.md 8(e)).  scaling = "weak".
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the flat Gaussian buffer is broadcast from
+rank 0 once, rank r renders view r of the same scene (yaw offsets of SURVEY.md 8(d)) forward + backward, the
+per-view gradients are summed with ONE all-reduce of the flat gradient buffer (112 MB at M = 1) and every rank
+applies the identical Adam step to its replica (--sync-mode owner selects the reduce-to-owner +
+per-step parameter broadcast variant instead).  The rasterizer itself never communicates.  scaling = "weak".
 
 Extra objects on the JSON line: "roofline" (dominant kernel, algorithmic bytes / hipEvent-measured launch
 time vs 8 TB/s), "cpu_baseline" (the CPU oracle on the same workload, host cores, rank 0 at N = 1 only),
@@ -81,6 +82,9 @@ def main():
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="activations / Adam as separate Torch ops (what the reference does) instead of the fused kernels")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE C2 style: colour+depth+silhouette forward only")
+    ap.add_argument("--sync-mode", default="allreduce", choices=("allreduce", "owner"),
+                    help="N > 1: 'allreduce' = sum the per-view gradients on every rank and step replicated Adam "
+                         "(one collective per step); 'owner' = reduce to rank 0, Adam there, broadcast the parameters")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = rehearsal of the multi-rank control flow (collectives staged through the host)")
     args = ap.parse_args()
@@ -152,8 +156,10 @@ def main():
                     torch.cat([model._features_dc, model._features_rest], 1))
         return model.activated()
 
+    owner_mode = n_gpus > 1 and args.sync_mode == "owner"
+
     def step():
-        if n_gpus > 1:
+        if owner_mode:
             MV.broadcast_gaussians(params, src=0)
         xyz, op, sc, rot, shs = activated()
         if args.forward_only:
@@ -167,11 +173,11 @@ def main():
         # upstream gradients injected directly (SURVEY.md 8(d) backward seeds): dL/dcolor = wc, dL/dacc = wa
         torch.autograd.backward([color, acc], [wc, wa])
         if n_gpus > 1:
-            MV.reduce_gradients(grads, dst=0)
+            MV.reduce_gradients(grads, dst=0, all_ranks=not owner_mode)
         if args.no_adam:
             grads.flat.zero_()
-        elif rank == 0:
-            opt.step()  # FusedAdam also clears the gradients it consumed
+        elif rank == 0 or not owner_mode:
+            opt.step()  # FusedAdam also clears the gradients it consumed; replicas stay identical under allreduce
         elif not args.torch_optimizer:
             grads.flat.zero_()
 
@@ -250,6 +256,7 @@ def main():
                                (args.workload, P, W, H, D,
                                 "forward only" if args.forward_only else "fwd+bwd + Adam step"),
                    "views_per_step": n_gpus, "parallelism": "view-parallel x%d" % n_gpus,
+                   "sync_mode": args.sync_mode if n_gpus > 1 else None,
                    "adam_in_step": not (args.no_adam or args.forward_only),
                    "optimizer": "torch ops" if args.torch_optimizer else "fused activations + fused Adam (HIP)"},
         "fps": round(1e3 / ms_per_step * n_gpus, 2),

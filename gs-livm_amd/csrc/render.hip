@@ -169,12 +169,9 @@ __global__ __launch_bounds__(64) void k_blend_forward(const FrameParams fp, cons
       c = splats[(size_t)id * SPLAT_F4 + 2];
       hit = (a.x + c.z >= qx0) && (a.x - c.z <= qx0 + 7.0f) && (a.y + c.w >= qy0) && (a.y - c.w <= qy0 + 7.0f);
     }
-    while (m) {
-      const int jj = __builtin_ctzll(m);
-      m &= m - 1;
-      const float4 ra = sA[jj];
-      const float4 rb = sB[jj];
-      const float4 rc = sC[jj];
+    // Visit loop, software-pipelined by hand: the LDS broadcast reads of the NEXT hit are issued before the
+    // current hit is blended (two register sets, no copies), so their latency hides behind ~30 VALU ops.
+    auto blend = [&](const float4 ra, const float4 rb, const float4 rc, const int jj) {
       const float dx = ra.x - pfx, dy = ra.y - pfy;
       const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
       const float alpha = fminf(0.99f, rb.y * __expf(power));
@@ -191,9 +188,29 @@ __global__ __launch_bounds__(64) void k_blend_forward(const FrameParams fp, cons
       A += wgt;
       T = ok ? test_T : T;
       last = ok ? (uint32_t)(base + jj + 1) : last;
-      if (__ballot(!done) == 0ull) {
-        wave_done = true;
-        break;
+      wave_done = __ballot(!done) == 0ull;
+    };
+    if (m) {
+      int j0 = __builtin_ctzll(m), j1;
+      m &= m - 1;
+      float4 a0 = sA[j0], b0 = sB[j0], c0 = sC[j0], a1, b1, c1;
+      for (;;) {
+        j1 = -1;
+        if (m) {
+          j1 = __builtin_ctzll(m);
+          m &= m - 1;
+          a1 = sA[j1]; b1 = sB[j1]; c1 = sC[j1];
+        }
+        blend(a0, b0, c0, j0);
+        if (wave_done || j1 < 0) break;
+        j0 = -1;
+        if (m) {
+          j0 = __builtin_ctzll(m);
+          m &= m - 1;
+          a0 = sA[j0]; b0 = sB[j0]; c0 = sC[j0];
+        }
+        blend(a1, b1, c1, j1);
+        if (wave_done || j0 < 0) break;
       }
     }
   }

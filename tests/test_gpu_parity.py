@@ -240,6 +240,24 @@ def test_screen_filling_splats_and_long_lists(gpu_device):
     assert (r[:, 1] - r[:, 0]).max() > 512 and fr.tiles_touched.max() >= 100
 
 
+def test_large_image_many_tile_bits(gpu_device):
+    """3000x1700: 188 x 107 = 20116 tiles -> 15 tile-id bits (two 8-bit sort passes), rect origins beyond 127,
+    partial tiles on both borders."""
+    sc = S.make_scene(30_000, 3000, 1700, 18, sh_degree=0)
+    O.set_threads(O.max_threads())
+    fr = O.forward(sc, keep_handle=False)
+    t, fwd = hip_forward(sc, gpu_device, debug=False)
+    check_forward(sc, fr, fwd, gpu_device)
+    assert int(fr.ranges.max()) == fr.R and fr.ranges.shape[0] == 188 * 107
+
+
+def test_tiny_images(gpu_device):
+    for (W, H) in ((1, 1), (5, 3), (16, 16), (17, 1)):
+        sc = S.make_scene(400, W, H, 19, sh_degree=1)
+        sc["means3D"][:, :2] *= 0.05  # everything lands on the few pixels there are
+        _full_check(sc, gpu_device, seed=19)
+
+
 def test_mark_visible(gpu_device):
     sc = S.make_scene(3000, 64, 48, 17)
     t = to_dev(sc, gpu_device)
