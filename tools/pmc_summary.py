@@ -23,8 +23,11 @@ def load(dirname, counter):
     path = glob.glob(dirname + "/*/*counter_collection.csv")[0]
     d = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        if r["Counter_Name"] == counter and r["Kernel_Name"].startswith("gsr::"):
-            name = r["Kernel_Name"].split("(")[0].replace("gsr::", "")
+        kn = r["Kernel_Name"]
+        if kn.startswith("void "):  # template instantiations are printed with their return type
+            kn = kn[5:]
+        if r["Counter_Name"] == counter and kn.startswith("gsr::"):
+            name = kn.split("(")[0].replace("gsr::", "").split("<")[0]
             d[name].append((float(r["Counter_Value"]), int(r["Grid_Size"])))
     return d
 
