@@ -4,6 +4,7 @@ Layout (only what the hot path needs):
   csrc/            hand-written HIP kernels (gfx950) + the C ABI (include/gsraster.h) + LibTorch binding
   _capi.py         ctypes binding of the C ABI (mirrors src/gs/rasterize_points.cu)
   rasterizer.py    host-side mirror of the reference operator surface (src/gs/rasterizer.cu)
+  loss.py          fused L1 + SSIM photometric loss (SURVEY.md 8(f) "next" row 2)
   model.py         fused activations + Adam for the caller's leaf tensors (SURVEY.md 8(f) "next" row 1)
   synthetic.py     synthetic scenes of SURVEY.md section 8(d) for tests and bench
   multiview.py     view-parallel sharding + the two RCCL exchange steps
@@ -14,6 +15,7 @@ The directory is named `gs-livm_amd`; import it as `gs_livm_amd` (alias module a
 from . import multiview, synthetic  # noqa: F401
 from ._capi import (GsrError, LIB_PATH, lib, mark_visible, profile_enable, profile_read,  # noqa: F401
                     rasterize_backward, rasterize_forward, state_views)
+from .loss import PhotometricLoss, photometric_loss, reference_window_1d  # noqa: F401
 from .model import FusedActivations, FusedAdam, GaussianParameters  # noqa: F401
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,  # noqa: F401
                          rasterize_gaussians)
@@ -36,5 +38,5 @@ def torch_ops():
     return mod
 
 
-__all__ = ["FusedActivations", "FusedAdam", "GaussianParameters", "GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_forward",
+__all__ = ["PhotometricLoss", "photometric_loss", "reference_window_1d", "FusedActivations", "FusedAdam", "GaussianParameters", "GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_forward",
            "rasterize_backward", "mark_visible", "state_views", "lib", "torch_ops", "synthetic", "multiview", "GsrError", "LIB_PATH"]

@@ -34,7 +34,8 @@ _lib = None
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_bytes", "gsr_image_bytes",
            "gsr_binning_bytes", "gsr_geometry_view_of", "gsr_binning_view_of", "gsr_image_view_of",
            "gsr_higher_msb", "gsr_last_error", "gsr_abi_version", "gsr_kernel_count", "gsr_kernel_name",
-           "gsr_profile_enable", "gsr_profile_read", "gsr_activate", "gsr_activate_backward", "gsr_adam_step")
+           "gsr_profile_enable", "gsr_profile_read", "gsr_activate", "gsr_activate_backward", "gsr_adam_step",
+           "gsr_photometric_loss", "gsr_photometric_loss_workspace")
 
 
 def lib():
@@ -78,6 +79,10 @@ def lib():
     L.gsr_activate.argtypes = [ci, ci] + [vp] * 9 + [vp]
     L.gsr_activate_backward.restype = ci
     L.gsr_activate_backward.argtypes = [ci, ci] + [vp] * 12 + [vp]
+    L.gsr_photometric_loss_workspace.restype = sz
+    L.gsr_photometric_loss_workspace.argtypes = [ci, ci, ci]
+    L.gsr_photometric_loss.restype = ci
+    L.gsr_photometric_loss.argtypes = [ci, ci, ci, vp, vp, C.POINTER(cf), cf, vp, vp, vp, sz, vp]
     L.gsr_adam_step.restype = ci
     L.gsr_adam_step.argtypes = [ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz),
                                 C.POINTER(cf), cf, cf, cf, ci, ci, vp]
@@ -289,3 +294,19 @@ def adam_step(params, grads, exp_avg, exp_avg_sq, lrs, beta1, beta2, eps, step, 
         assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
     _check(lib().gsr_adam_step(n, arr(params), arr(grads), arr(exp_avg), arr(exp_avg_sq), numel, lr, float(beta1),
                                float(beta2), float(eps), int(step), int(bool(zero_grads)), _stream()))
+
+
+def photometric_loss(img, gt, window11, lambda_dssim, want_grad=True):
+    """(1 - lambda) * L1 + lambda * (1 - SSIM) in three launches (include/gsraster.h).
+    Returns (out3 = [loss, l1, ssim] device tensor, dL_dimg or None)."""
+    assert img.dim() == 3 and img.shape == gt.shape and img.is_cuda
+    Cn, H, W = (int(x) for x in img.shape)
+    img, gt = img.contiguous(), gt.contiguous()
+    nbytes = int(lib().gsr_photometric_loss_workspace(Cn, H, W))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=img.device)
+    out3 = torch.empty(3, dtype=torch.float32, device=img.device)
+    grad = torch.empty_like(img) if want_grad else None
+    win = (C.c_float * 11)(*[float(x) for x in window11])
+    _check(lib().gsr_photometric_loss(Cn, H, W, _ptr(img), _ptr(gt), win, float(lambda_dssim), _ptr(out3), _ptr(grad),
+                                      _ptr(ws), nbytes, _stream()))
+    return out3, grad

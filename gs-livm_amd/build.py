@@ -30,6 +30,7 @@ UNITS = {
     # into mov_dpp + pk_add: measured 9 % slower on k_blend_backward, so it is off for the blend kernels.
     "render.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"] + os.environ.get("GSR_EXTRA_RENDER_FLAGS", "").split(),
     "optimizer.hip": [],
+    "loss.hip": [],
     "api.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "gsr_internal.hpp"), os.path.join(ROOT, "include", "gsraster.h")]

@@ -60,7 +60,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top", "k_sort_scatter", "k_tile_ranges", "k_blend_forward",
     "k_blend_backward", "k_compact_touched", "k_gather_records", "k_gaussian_backward", "k_mark_visible", "k_sort_hist[depth]",
     "k_sort_scan_chunks[depth]", "k_sort_scan_top[depth]", "k_sort_scatter[depth]", "k_activate",
-    "k_activate_backward", "k_adam"};
+    "k_activate_backward", "k_adam", "k_loss_forward", "k_loss_finalize", "k_loss_backward"};
 
 extern "C" {
 
@@ -303,6 +303,25 @@ int gsr_adam_step(int n_tensors, float* const* params, float* const* grads, floa
       return fail(GSR_ERR_INVALID_ARGUMENT, "null tensor pointer");
   HIP_TRY(launch_adam(n_tensors, params, grads, exp_avg, exp_avg_sq, numel, lr, beta1, beta2, eps, step, zero_grads,
                       (hipStream_t)stream_));
+  return GSR_OK;
+}
+
+size_t gsr_photometric_loss_workspace(int channels, int height, int width) {
+  if (channels <= 0 || height <= 0 || width <= 0) return 0;
+  return loss_workspace_bytes(channels, height, width);
+}
+
+int gsr_photometric_loss(int channels, int height, int width, const float* img, const float* gt,
+                         const float* window11_host, float lambda_dssim, float* loss_out3, float* dL_dimg,
+                         char* workspace, size_t workspace_bytes, void* stream_) {
+  g_err[0] = 0;
+  if (channels <= 0 || height <= 0 || width <= 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad image shape");
+  if (!img || !gt || !window11_host || !loss_out3 || !workspace) return fail(GSR_ERR_INVALID_ARGUMENT, "null pointer");
+  if (workspace_bytes < loss_workspace_bytes(channels, height, width))
+    return fail(GSR_ERR_INVALID_ARGUMENT, "workspace too small: need %zu bytes",
+                loss_workspace_bytes(channels, height, width));
+  HIP_TRY(launch_photometric_loss(channels, height, width, img, gt, window11_host, lambda_dssim, loss_out3, dL_dimg,
+                                  workspace, (hipStream_t)stream_));
   return GSR_OK;
 }
 

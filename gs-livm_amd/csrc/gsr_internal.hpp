@@ -211,6 +211,10 @@ hipError_t launch_activate_backward(int P, int M, const float* rotation_raw, con
                                     const float* g_opac, const float* g_shs, float* g_scaling_raw,
                                     float* g_rotation_raw, float* g_opacity_raw, float* g_f_dc, float* g_f_rest,
                                     hipStream_t s);
+// loss.hip ("next" row: fused L1 + SSIM photometric loss)
+size_t loss_workspace_bytes(int C, int H, int W);
+hipError_t launch_photometric_loss(int C, int H, int W, const float* img, const float* gt, const float* window11,
+                                   float lambda, float* loss_out3, float* dL_dimg, char* workspace, hipStream_t s);
 hipError_t launch_adam(int n, float* const* params, float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const size_t* numel, const float* lr, float beta1, float beta2,
                        float eps, int step, int zero_grads, hipStream_t s);
@@ -224,7 +228,7 @@ enum KernelId {
   K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DEPTH_KEYS, K_SORTED_SUMS, K_SORTED_OFFSETS, K_EMIT_CHUNKS, K_EMIT, K_SORT_HIST,
   K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_COMPACT_TOUCHED,
   K_GATHER_RECORDS, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_DSORT_HIST, K_DSORT_SCAN_CHUNKS, K_DSORT_SCAN_TOP,
-  K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_COUNT
+  K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_LOSS_FWD, K_LOSS_FINALIZE, K_LOSS_BWD, K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);

@@ -149,6 +149,19 @@ int gsr_adam_step(int n_tensors, float* const* params, float* const* grads, floa
                   float* const* exp_avg_sq, const size_t* numel, const float* lr, float beta1, float beta2, float eps,
                   int step, int zero_grads, void* stream);
 
+/* ---- "next" row: the photometric loss that follows every render, fused ----
+ *   L = (1 - lambda) * mean|img - gt| + lambda * (1 - mean(SSIM(img, gt)))
+ * replaces gaussian_splatting::l1_loss + ::ssim (include/gs/gs/loss_utils.cuh:11-13,43-70; combined at
+ * src/liw/lioOptimization.cpp:1705-1710) and their autograd: five grouped 11x11 conv2d per view there, three
+ * launches here.  img/gt: [channels][H][W] device f32; window11_host: the 11 taps of the separable window on the
+ * HOST (the reference's 2-D window is their outer product, loss_utils.cuh:33-37; it need not be symmetric);
+ * zero padding 5 like conv2d(padding = window_size/2).  loss_out3 (device) = {L, mean L1, mean SSIM};
+ * dL_dimg (nullable) = dL/dimg for upstream gradient 1.  Deterministic (fixed-order reductions). */
+size_t gsr_photometric_loss_workspace(int channels, int height, int width);
+int gsr_photometric_loss(int channels, int height, int width, const float* img, const float* gt,
+                         const float* window11_host, float lambda_dssim, float* loss_out3, float* dL_dimg,
+                         char* workspace, size_t workspace_bytes, void* stream);
+
 /* Optional per-kernel device timing (hipEvent pairs recorded on the launch stream around every
  * kernel launch while enabled).  Measurement aid for bench.py's roofline line; the reference has only
  * host wall-clock timers (include/common/timer/timer.h:36-52).  Not thread-safe; off by default.
