@@ -67,6 +67,7 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
         "k_activate": P * 4 * (11 + 3 * M) * 2 - P * 24,          # xyz is not touched
         "k_activate_backward": P * 4 * (8 + 3 * M) * 2 + P * 4 * 8,
         "k_adam": P * 4 * (11 + 3 * M) * 7,                       # p, g, m, v read; p, m, v (+ zeroed g) written
+        "k_loss_forward": W * H * 3 * 4 * 5, "k_loss_backward": W * H * 3 * 4 * 6, "k_loss_finalize": 0,
     }
 
 
@@ -82,6 +83,9 @@ def main():
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="activations / Adam as separate Torch ops (what the reference does) instead of the fused kernels")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE C2 style: colour+depth+silhouette forward only")
+    ap.add_argument("--loss", default="seeded", choices=("seeded", "photometric"),
+                    help="seeded: inject the fixed upstream gradients of SURVEY.md 8(d); photometric: the reference's "
+                         "0.8*L1 + 0.2*(1-SSIM) against a fixed random target (fused HIP loss kernels)")
     ap.add_argument("--sync-mode", default="allreduce", choices=("allreduce", "owner"),
                     help="N > 1: 'allreduce' = sum the per-view gradients on every rank and step replicated Adam "
                          "(one collective per step); 'owner' = reduce to rank 0, Adam there, broadcast the parameters")
@@ -148,6 +152,8 @@ def main():
     dcol, dacc = S.make_upstream_grads(W, H, seed + rank)
     wc, wa = torch.from_numpy(dcol).to(dev), torch.from_numpy(dacc).to(dev)
     means2D = torch.zeros((P, 3), device=dev, requires_grad=True)  # gradient sink, as render_utils.cuh:39-40
+    target = torch.rand((3, H, W), generator=torch.Generator().manual_seed(seed)).to(dev)  # --loss photometric
+    window = G.reference_window_1d()
 
     def activated():
         if args.torch_optimizer:  # the reference's getters as separate Torch ops (gaussian.cuh:40-54)
@@ -170,8 +176,10 @@ def main():
         means2D.grad = None
         if args.torch_optimizer:
             grads.flat.zero_()
-        # upstream gradients injected directly (SURVEY.md 8(d) backward seeds): dL/dcolor = wc, dL/dacc = wa
-        torch.autograd.backward([color, acc], [wc, wa])
+        if args.loss == "photometric":  # lioOptimization.cpp:1705-1710 with lambda_dssim = 0.2
+            G.photometric_loss(color, target, 0.2, window).backward()
+        else:  # upstream gradients injected directly (SURVEY.md 8(d) backward seeds): dL/dcolor = wc, dL/dacc = wa
+            torch.autograd.backward([color, acc], [wc, wa])
         if n_gpus > 1:
             MV.reduce_gradients(grads, dst=0, all_ranks=not owner_mode)
         if args.no_adam:
@@ -258,7 +266,8 @@ def main():
                    "views_per_step": n_gpus, "parallelism": "view-parallel x%d" % n_gpus,
                    "sync_mode": args.sync_mode if n_gpus > 1 else None,
                    "adam_in_step": not (args.no_adam or args.forward_only),
-                   "optimizer": "torch ops" if args.torch_optimizer else "fused activations + fused Adam (HIP)"},
+                   "optimizer": "torch ops" if args.torch_optimizer else "fused activations + fused Adam (HIP)",
+                   "loss": args.loss},
         "fps": round(1e3 / ms_per_step * n_gpus, 2),
         "roofline": roofline,
         "whole_path": {"kernel_ms_per_step": round(raster_ms, 4), "algorithmic_GB_per_step": round(b_path / 1e9, 3),

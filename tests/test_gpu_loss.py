@@ -28,16 +28,6 @@ def ref_loss(img, gt, w1d, lam):
     return (1 - lam) * (img - gt).abs().mean() + lam * (1 - ref_ssim(img, gt, w1d))
 
 
-def test_reference_window_quirk():
-    """loss_utils.cuh:24-31: floor((x - 11)/2) -> exponents 6,5,5,4,4,3,3,2,2,1,1: not symmetric."""
-    w = G.reference_window_1d()
-    k = np.array([6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1], np.float64)
-    want = np.exp(-k * k / 4.5)
-    want /= want.sum()
-    assert np.allclose(w.numpy(), want, atol=1e-7) and abs(float(w.sum()) - 1) < 1e-6
-    assert not np.allclose(w.numpy(), w.numpy()[::-1])
-
-
 @pytest.mark.parametrize("shape,lam", [((3, 45, 67), 0.2), ((3, 300, 200), 0.2), ((1, 16, 16), 0.5), ((3, 9, 7), 0.0),
                                        ((3, 128, 130), 1.0)])
 def test_fused_loss_matches_torch(shape, lam, gpu_device):

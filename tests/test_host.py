@@ -110,6 +110,17 @@ def test_gaussian_buffer_layout():
     assert (buf.flat[100 * 22:100 * 23] == 0.25).all()
 
 
+def test_reference_window_quirk():
+    """loss_utils.cuh:24-31: floor((x - 11)/2) -> exponents 6,5,5,4,4,3,3,2,2,1,1: not symmetric."""
+    w = G.reference_window_1d()
+    k = np.array([6, 5, 5, 4, 4, 3, 3, 2, 2, 1, 1], np.float64)
+    want = np.exp(-k * k / 4.5)
+    want /= want.sum()
+    assert np.allclose(w.numpy(), want, atol=1e-7) and abs(float(w.sum()) - 1) < 1e-6
+    assert not np.allclose(w.numpy(), w.numpy()[::-1])
+
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
