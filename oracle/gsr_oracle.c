@@ -8,10 +8,15 @@
  *
  * PARITY STATUS: "parity unpinned".  The reference (CUDA, needs nvcc + CUB +
  * CUDA headers) cannot be built in this image and ships no tests, golden
- * vectors or fixtures for this path.  The only reference
- * output available is the single-Gaussian known answer the survey recorded
- * (radius 33, xy (340.8333,196.8333), conic
- * (0.008766,0.000005,0.053982), 25 tiles); tests/test_oracle.py checks it.
+ * vectors or fixtures for this path.  What IS pinned:
+ *  - the single-Gaussian known answer the survey recorded from the reference
+ *    (radius 33, xy (340.8333,196.8333), conic
+ *    (0.008766,0.000005,0.053982), 25 tiles): tests/test_oracle.py;
+ *  - the 3x3 product / transpose / dot / length helpers below, bit for bit
+ *    against the reference's own vendored GLM (oracle/ref_glm/check_glm.cpp is
+ *    compiled straight from /root/reference/external/glm into oracle/_ref/).
+ * Everything else (culling rules, EWA, SH, sort, blending, the whole backward)
+ * is a restatement checked only against itself.
  *
  * Every function cites the reference file:line it restates (paths relative to
  * /root/reference).  Arithmetic is IEEE f32 with the reference's evaluation
@@ -735,6 +740,28 @@ uint32_t gsro_higher_msb(uint32_t n) {
   if (n >> msb) msb++;
   return msb;
 }
+
+/* Test hooks: the small-matrix helpers, exposed so tests/test_oracle.py can compare them bit for bit with the
+ * reference's vendored GLM (oracle/ref_glm/check_glm.cpp).  Matrices are 9 floats, [col][row]. */
+void gsro_test_m3_mul(const float* a, const float* b, float* o) {
+  m3 A, B;
+  memcpy(A.c, a, sizeof(A.c));
+  memcpy(B.c, b, sizeof(B.c));
+  m3 P = m3_mul(&A, &B);
+  memcpy(o, P.c, sizeof(P.c));
+}
+void gsro_test_m3_ttm(const float* a, const float* b, float* o) { /* transpose(A) * transpose(B) * A */
+  m3 A, B;
+  memcpy(A.c, a, sizeof(A.c));
+  memcpy(B.c, b, sizeof(B.c));
+  m3 At = m3_t(&A), Bt = m3_t(&B);
+  m3 L = m3_mul(&At, &Bt);
+  m3 P = m3_mul(&L, &A);
+  memcpy(o, P.c, sizeof(P.c));
+}
+float gsro_test_dot3(const float* u, const float* v) { return u[0] * v[0] + u[1] * v[1] + u[2] * v[2]; }
+float gsro_test_dot4(const float* p, const float* q) { return (p[0] * q[0] + p[1] * q[1]) + (p[2] * q[2] + p[3] * q[3]); }
+float gsro_test_len3(const float* u) { return sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]); }
 
 /* accessors for the ctypes wrapper (oracle/oracle.py) */
 int gsro_num_rendered(const gsro_frame* f) { return f->R; }

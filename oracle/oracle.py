@@ -21,6 +21,14 @@ def build(force=False):
     return _SO
 
 
+def build_ref():
+    """oracle/_ref/check_glm: compiled from the reference's vendored GLM where /root/reference exists (the build
+    container); returns its path or None."""
+    subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    p = os.path.join(_HERE, "_ref", "check_glm")
+    return p if os.path.exists(p) else None
+
+
 _lib = None
 
 

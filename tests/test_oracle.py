@@ -60,6 +60,45 @@ def test_oracle_reproduces_golden(name):
         assert np.allclose(v, ref, atol=1e-6 * float(np.abs(ref).max()), rtol=1e-5), k
 
 
+def test_small_matrix_helpers_match_the_references_glm():
+    """oracle/_ref/check_glm is built from the reference's own vendored GLM (external/glm) and dumps mat3
+    products, dot products and lengths of LCG-random inputs; the oracle's restated helpers must reproduce them
+    bit for bit.  Skipped where neither /root/reference nor a prebuilt binary exists."""
+    import ctypes as C
+    import subprocess
+    exe = O.build_ref()
+    if exe is None:
+        pytest.skip("reference GLM not available and no prebuilt oracle/_ref/check_glm")
+    n = 2000
+    ref = np.frombuffer(subprocess.check_output([exe, str(n)]), dtype=np.float32).reshape(n, 22)
+    L = O.lib()
+    for f in ("gsro_test_dot3", "gsro_test_dot4", "gsro_test_len3"):
+        getattr(L, f).restype = C.c_float
+    state = np.uint32(12345)
+
+    def rnd():
+        nonlocal state
+        state = np.uint32((int(state) * 1664525 + 1013904223) & 0xFFFFFFFF)
+        return np.float32(np.float32(int(state) >> 8) * np.float32(1.0 / 16777216.0)) * np.float32(4.0) - np.float32(2.0)
+
+    fp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    for it in range(n):
+        A = np.array([rnd() for _ in range(9)], np.float32)
+        B = np.array([rnd() for _ in range(9)], np.float32)
+        u = np.array([rnd() for _ in range(3)], np.float32)
+        v = np.array([rnd() for _ in range(3)], np.float32)
+        p = np.array([rnd() for _ in range(4)], np.float32)
+        q = np.array([rnd() for _ in range(4)], np.float32)
+        P, Q = np.zeros(9, np.float32), np.zeros(9, np.float32)
+        L.gsro_test_m3_mul(fp(A), fp(B), fp(P))
+        L.gsro_test_m3_ttm(fp(A), fp(B), fp(Q))
+        ln = np.float32(L.gsro_test_len3(fp(u)))
+        d = u / ln
+        got = np.concatenate([P, Q, [L.gsro_test_dot3(fp(u), fp(v)), L.gsro_test_dot4(fp(p), fp(q)), ln,
+                                     np.float32(np.float32(d[0] + d[1]) + d[2])]]).astype(np.float32)
+        assert np.array_equal(got.view(np.uint32), ref[it].view(np.uint32)), it
+
+
 def test_higher_msb_matches_survey_table():
     # SURVEY.md Appendix C: tiles 1200 / 3600 / 8160 -> bit 11 / 12 / 13
     assert [O.higher_msb(n) for n in (1200, 3600, 8160)] == [11, 12, 13]
