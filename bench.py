@@ -83,6 +83,9 @@ def main():
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="activations / Adam as separate Torch ops (what the reference does) instead of the fused kernels")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE C2 style: colour+depth+silhouette forward only")
+    ap.add_argument("--host", default="cpp", choices=("cpp", "python"),
+                    help="operator surface used for the rasterizer: the C++/LibTorch binding GS-LIVM would link "
+                         "(csrc/torch_binding.cpp) or the Python mirror over ctypes")
     ap.add_argument("--loss", default="seeded", choices=("seeded", "photometric"),
                     help="seeded: inject the fixed upstream gradients of SURVEY.md 8(d); photometric: the reference's "
                          "0.8*L1 + 0.2*(1-SSIM) against a fixed random target (fused HIP loss kernels)")
@@ -133,8 +136,10 @@ def main():
                                  v["opacities"])
     leaves = dict(means3D=model._xyz, features_dc=model._features_dc, features_rest=model._features_rest,
                   scales=model._scaling, rotations=model._rotation, opacities=model._opacity)
-    for k, p in leaves.items():
-        p.grad = grads.views[k]  # autograd accumulates in place -> gradients live in one flat buffer too
+    flat_grads = n_gpus > 1  # one flat gradient buffer = one collective; a single GPU lets autograd hand over its
+    if flat_grads:           # gradient tensors as they are (no accumulate kernels, nothing to zero)
+        for k, p in leaves.items():
+            p.grad = grads.views[k]
     # groups / learning rates of GaussianModel::Training_setup (src/gs/gaussian.cu:396-428) with the values of
     # config/basic_common.yaml:54-62, eps 1e-15
     groups = [gr for gr in model.param_groups() if gr["params"][0].numel()]
@@ -148,7 +153,16 @@ def main():
                                                torch.from_numpy(cam["viewmatrix"]).to(dev),
                                                torch.from_numpy(cam["projmatrix"]).to(dev), D,
                                                torch.from_numpy(cam["campos"]).to(dev), False)
-    raster = G.GaussianRasterizer(settings)
+    if args.host == "cpp":
+        T = G.torch_ops()
+        raster_cpp = T.GaussianRasterizer(T.GaussianRasterizationSettings(
+            H, W, cam["tanfovx"], cam["tanfovy"], bg, 1.0, settings.viewmatrix, settings.projmatrix, D,
+            settings.camera_center, False))
+
+        def raster(xyz, m2d, op, shs, scales, rotations):
+            return raster_cpp.forward(xyz, m2d, op, shs=shs, scales=scales, rotations=rotations)
+    else:
+        raster = G.GaussianRasterizer(settings)
     dcol, dacc = S.make_upstream_grads(W, H, seed + rank)
     wc, wa = torch.from_numpy(dcol).to(dev), torch.from_numpy(dacc).to(dev)
     means2D = torch.zeros((P, 3), device=dev, requires_grad=True)  # gradient sink, as render_utils.cuh:39-40
@@ -174,7 +188,7 @@ def main():
             return
         color, radii, depth, acc = raster(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
         means2D.grad = None
-        if args.torch_optimizer:
+        if args.torch_optimizer and flat_grads:
             grads.flat.zero_()
         if args.loss == "photometric":  # lioOptimization.cpp:1705-1710 with lambda_dssim = 0.2
             G.photometric_loss(color, target, 0.2, window).backward()
@@ -182,12 +196,16 @@ def main():
             torch.autograd.backward([color, acc], [wc, wa])
         if n_gpus > 1:
             MV.reduce_gradients(grads, dst=0, all_ranks=not owner_mode)
-        if args.no_adam:
+        if not args.no_adam and (rank == 0 or not owner_mode):
+            if args.torch_optimizer:
+                opt.step()
+            else:
+                opt.step(zero_grads=flat_grads)  # clears the flat buffer it consumed; replicas stay identical
+        elif flat_grads:
             grads.flat.zero_()
-        elif rank == 0 or not owner_mode:
-            opt.step()  # FusedAdam also clears the gradients it consumed; replicas stay identical under allreduce
-        elif not args.torch_optimizer:
-            grads.flat.zero_()
+        if not flat_grads:
+            for p in leaves.values():
+                p.grad = None
 
     def barrier():
         torch.cuda.synchronize()
@@ -267,7 +285,7 @@ def main():
                    "sync_mode": args.sync_mode if n_gpus > 1 else None,
                    "adam_in_step": not (args.no_adam or args.forward_only),
                    "optimizer": "torch ops" if args.torch_optimizer else "fused activations + fused Adam (HIP)",
-                   "loss": args.loss},
+                   "loss": args.loss, "host": args.host},
         "fps": round(1e3 / ms_per_step * n_gpus, 2),
         "roofline": roofline,
         "whole_path": {"kernel_ms_per_step": round(raster_ms, 4), "algorithmic_GB_per_step": round(b_path / 1e9, 3),
