@@ -308,7 +308,8 @@ def cpu_baseline(g, cam, dcol, dacc, W, H, D):
     forward + backward on all host cores available to this process."""
     from oracle import oracle as O
     sc = dict(g, **cam, bg=np.ones(3, np.float32), scale_modifier=1.0, colors_precomp=None, cov3D_precomp=None)
-    threads = min(O.max_threads(), len(os.sched_getaffinity(0)))
+    # the box's CPU share for one GPU is 16 cores: never spawn more workers than that
+    threads = min(O.max_threads(), len(os.sched_getaffinity(0)), 16)
     O.set_threads(threads)
     t0 = time.perf_counter()
     fr = O.forward(sc)

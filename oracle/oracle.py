@@ -46,6 +46,9 @@ def lib():
             fn = getattr(_lib, "gsro_" + name)
             fn.restype = C.c_void_p
             fn.argtypes = [C.c_void_p]
+        # never more OpenMP workers than a GPU box's CPU share (16 cores per GPU), whatever the host exposes
+        _lib.gsro_max_threads.restype = C.c_int
+        _lib.gsro_set_threads(C.c_int(min(int(_lib.gsro_max_threads()), len(os.sched_getaffinity(0)), 16)))
     return _lib
 
 

@@ -244,7 +244,7 @@ def test_large_image_many_tile_bits(gpu_device):
     """3000x1700: 188 x 107 = 20116 tiles -> 15 tile-id bits (two 8-bit sort passes), rect origins beyond 127,
     partial tiles on both borders."""
     sc = S.make_scene(30_000, 3000, 1700, 18, sh_degree=0)
-    O.set_threads(O.max_threads())
+    O.set_threads(min(O.max_threads(), 16))
     fr = O.forward(sc, keep_handle=False)
     t, fwd = hip_forward(sc, gpu_device, debug=False)
     check_forward(sc, fr, fwd, gpu_device)
@@ -437,7 +437,7 @@ def test_c2_full_parity_with_oracle(gpu_device):
     """BASELINE C2 (500 k Gaussians, 1280x720): complete forward parity incl. tile ranges, all threads of the host."""
     P, W, H, seed = S.CONFIGS["C2"]
     sc = S.make_scene(P, W, H, seed)
-    O.set_threads(O.max_threads())
+    O.set_threads(min(O.max_threads(), 16))  # the GPU box's CPU share
     fr = O.forward(sc, keep_handle=False)
     t, fwd = hip_forward(sc, gpu_device, debug=False)
     check_forward(sc, fr, fwd, gpu_device)
