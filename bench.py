@@ -45,6 +45,7 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
     """Algorithmic HBM bytes per LAUNCH of every kernel (DESIGN.md section 5 states each figure).
     R = instances, R_bwd = sum over tiles of tile_last (list entries the backward has to walk)."""
+    kb = 2 if tiles <= 65536 else 4
     return {
         "k_preprocess": P * (44 + 12 * M) + P * 8 + P_vis * 77,   # in: 56 B @M=1; out: radii+tiles, 48-B splat, cov3D, depth, clamp
         "k_scan_block_sums": (P // 256 + 1) * 8,
@@ -54,10 +55,11 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
         "k_sorted_block_sums": P * 8,
         "k_sorted_offsets": P * 8 + P_vis * 20 + P * 12 + P_vis * 8,
         "k_emit_chunks": P * 8,
-        "k_emit": R * 8 + P_vis * 16,
-        "k_sort_hist": R * 4, "k_sort_scatter": R * 16,           # (u32 tile, u32 id): read 8 B + write 8 B per pass
+        # tile ids are 16-bit when the image has <= 65536 tiles (kb bytes per key), Gaussian ids 32-bit
+        "k_emit": R * (kb + 4) + P_vis * 16,
+        "k_sort_hist": R * kb, "k_sort_scatter": R * 2 * (kb + 4),  # (tile, id): read + write per pass
         "k_sort_scan_chunks": (R // 4096 + 1) * 2048, "k_sort_scan_top": 0,
-        "k_tile_ranges": R * 4 + tiles * 8,
+        "k_tile_ranges": R * kb + tiles * 8,
         "k_blend_forward": R * 44 + W * H * 28,                   # full lists (early exit reads fewer)
         "k_blend_backward": W * H * 24 + R_bwd * (40 + 36),       # SURVEY.md 8(d) per-instance figures x walked entries
         "k_compact_touched": P * 1 + P_vis * 0,

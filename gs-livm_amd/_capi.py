@@ -22,7 +22,7 @@ class GeometryView(C.Structure):
 
 
 class BinningView(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("tile_ids", "point_list")]
+    _fields_ = [("tile_ids", C.c_void_p), ("point_list", C.c_void_p), ("tile_id_bytes", C.c_int)]
 
 
 class ImageView(C.Structure):
@@ -63,7 +63,7 @@ def lib():
     L.gsr_image_bytes.restype = sz
     L.gsr_image_bytes.argtypes = [ci, ci]
     L.gsr_geometry_view_of.argtypes = [vp, ci, C.POINTER(GeometryView)]
-    L.gsr_binning_view_of.argtypes = [vp, ci, C.POINTER(BinningView)]
+    L.gsr_binning_view_of.argtypes = [vp, ci, ci, ci, C.POINTER(BinningView)]
     L.gsr_image_view_of.argtypes = [vp, ci, ci, C.POINTER(ImageView)]
     L.gsr_higher_msb.restype = C.c_uint32
     L.gsr_higher_msb.argtypes = [C.c_uint32]
@@ -233,8 +233,11 @@ def state_views(geomBuffer, binningBuffer, imageBuffer, P, R, W, H):
                    n_contrib=_sub(imageBuffer, iv.n_contrib, W * H, torch.int32).view(H, W),
                    quad_last=_sub(imageBuffer, iv.quad_last, T * 4, torch.int32).view(T, 4))
         if R:
-            _check(L.gsr_binning_view_of(_ptr(binningBuffer), R, C.byref(bv)))
-            tile_ids = _sub(binningBuffer, bv.tile_ids, R, torch.int32)
+            _check(L.gsr_binning_view_of(_ptr(binningBuffer), R, W, H, C.byref(bv)))
+            if bv.tile_id_bytes == 2:  # uint16 tile ids (read as int16, then widened without sign)
+                tile_ids = _sub(binningBuffer, bv.tile_ids, R, torch.int16).int() & 0xFFFF
+            else:
+                tile_ids = _sub(binningBuffer, bv.tile_ids, R, torch.int32)
             point_list = _sub(binningBuffer, bv.point_list, R, torch.int32)
             # the reference's 64-bit sorted keys, recomposed: (tile << 32) | bits(depth of the instance's Gaussian)
             dbits = out["depths"].view(torch.int32)[point_list.long()].long() & 0xFFFFFFFF

@@ -5,7 +5,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <chrono>
 #include <vector>
 
 #include "gsr_internal.hpp"
@@ -171,41 +173,80 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
   STAGE(launch_preprocess(fp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
                           projmatrix, cam_pos, g, radii, stream));
-  STAGE(launch_scan_block_sums(g.block_sums, nb, g.total, stream));
-  // R must be known on the host to size the binning blob: one blocking 4-byte read-back, exactly
-  // where the reference has its cudaMemcpy (rasterizer_impl.cu:277).  The per-Gaussian depth sort
-  // does not depend on R and is enqueued first, so the GPU keeps working while the host waits.
-  static thread_local uint32_t* pinned = nullptr;  // page-locked so the copy is truly asynchronous
-  if (!pinned && hipHostMalloc(reinterpret_cast<void**>(&pinned), 64, hipHostMallocDefault) != hipSuccess) {
-    pinned = nullptr;
-    (void)hipGetLastError();
+  // R must be known on the host to size the binning blob, where the reference has its blocking
+  // cudaMemcpy (rasterizer_impl.cu:277).  Here the scan kernel stores (ticket, R) into a page-locked,
+  // host-mapped word and the host polls that word: no copy engine, no completion interrupt (whose
+  // wake-up latency was measured at up to 30 ms on virtualised hosts), and the host gets R as soon as
+  // the scan retires -- the per-Gaussian depth sort, which does not depend on R, is already enqueued
+  // behind it and runs while the host sizes and allocates the binning blob.
+  static thread_local unsigned long long* mailbox = nullptr;  // host pointer
+  static thread_local unsigned long long* mailbox_dev = nullptr;
+  static thread_local uint32_t ticket = 0;
+  if (!mailbox) {
+    void* h = nullptr;
+    void* d = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess)
+      return fail(GSR_ERR_HIP, "cannot allocate the host-mapped mailbox: %s", hipGetErrorString(hipGetLastError()));
+    mailbox = static_cast<unsigned long long*>(h);
+    mailbox_dev = static_cast<unsigned long long*>(d);
+    *mailbox = 0;
   }
-  uint32_t R_stack = 0;
-  uint32_t* R_dst = pinned ? pinned : &R_stack;
-  HIP_TRY(hipMemcpyAsync(R_dst, g.total, sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+  ticket = ticket == 0xFFFFFFFFu ? 1u : ticket + 1u;  // never 0: the mailbox starts at ticket 0
+  STAGE(launch_scan_block_sums(g.block_sums, nb, g.total, mailbox_dev, ticket, stream));
   STAGE(launch_depth_keys(fp, g, g.dkeysA, g.order, stream));
   STAGE(launch_sort_pairs(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, 32, /*start_in_A=*/true,
-                          /*is_depth_sort=*/true, stream));
+                          /*is_depth_sort=*/true, /*key16=*/false, stream));
   STAGE(launch_sorted_block_sums(fp, g, stream));
-  STAGE(launch_scan_block_sums(g.block_sums2, nb, g.total + 1, stream));
+  STAGE(launch_scan_block_sums(g.block_sums2, nb, g.total + 1, nullptr, 0, stream));
   STAGE(launch_sorted_offsets(fp, g, stream));
-  HIP_TRY(hipStreamSynchronize(stream));
-  const uint32_t R_host = *R_dst;
+  uint32_t R_host = 0;
+  const std::chrono::steady_clock::time_point t_enqueued = std::chrono::steady_clock::now();
+  {
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = t_enqueued;
+    clk::time_point next_query = t0 + std::chrono::milliseconds(2);
+    for (;;) {
+      const unsigned long long v = __atomic_load_n(mailbox, __ATOMIC_ACQUIRE);
+      if ((uint32_t)(v >> 32) == ticket) { R_host = (uint32_t)v; break; }
+      __builtin_ia32_pause();
+      if (clk::now() < next_query) continue;
+      // slow path (every 2 ms): notice a faulted or drained stream instead of spinning for ever
+      const hipError_t q = hipStreamQuery(stream);
+      if (q == hipSuccess) {  // everything enqueued has retired, so the word has been stored
+        const unsigned long long v2 = __atomic_load_n(mailbox, __ATOMIC_ACQUIRE);
+        if ((uint32_t)(v2 >> 32) != ticket) return fail(GSR_ERR_HIP, "instance count was not published");
+        R_host = (uint32_t)v2;
+        break;
+      }
+      if (q != hipErrorNotReady) return fail(GSR_ERR_HIP, "stream failed: %s", hipGetErrorString(q));
+      next_query = clk::now() + std::chrono::milliseconds(2);
+    }
+  }
   if (R_host > 0x7fffffffu) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31 splat instances");
   const int R = (int)R_host;
 
+  static const bool host_trace = getenv("GSR_HOST_TRACE") != nullptr;  // diagnostics: host-side waits
+  const std::chrono::steady_clock::time_point ta = std::chrono::steady_clock::now();
   char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(R));
+  if (host_trace) {
+    const std::chrono::steady_clock::time_point tb = std::chrono::steady_clock::now();
+    fprintf(stderr, "[gsr] R=%d wait %.1f us, binning alloc %.1f us\n", R,
+            std::chrono::duration<double, std::micro>(ta - t_enqueued).count(),
+            std::chrono::duration<double, std::micro>(tb - ta).count());
+  }
   if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
   BinningState b = BinningState::carve(bblob, (size_t)R);
 
   const int tiles = fp.gx * fp.gy;
   const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
   const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
+  const bool key16 = tiles <= 65536;  // tile ids fit 16 bits for every image up to 4096 x 4096
   STAGE(launch_emit(fp, g, R, b.chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB,
-                    stream));
+                    key16, stream));
   STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, R, tile_bits, start_in_A,
-                          /*is_depth_sort=*/false, stream));
-  STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, tiles, stream));
+                          /*is_depth_sort=*/false, key16, stream));
+  STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, tiles, key16, stream));
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
   return R;
 }
@@ -339,10 +380,12 @@ int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out) {
   return GSR_OK;
 }
 
-int gsr_binning_view_of(char* binning_buffer, int R, gsr_binning_view* out) {
-  if (!binning_buffer || !out || R < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad argument");
+int gsr_binning_view_of(char* binning_buffer, int R, int width, int height, gsr_binning_view* out) {
+  if (!binning_buffer || !out || R < 0 || width <= 0 || height <= 0)
+    return fail(GSR_ERR_INVALID_ARGUMENT, "bad argument");
   BinningState b = BinningState::carve(binning_buffer, (size_t)R);
   out->tile_ids = b.tkeysA;
+  out->tile_id_bytes = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE) <= 65536 ? 2 : 4;
   out->point_list = b.point_list;
   return GSR_OK;
 }

@@ -178,19 +178,20 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
                              const float* opacities, const float* shs, const float* cov3D_precomp,
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,
                              GeomState g, int* radii_out, hipStream_t s);
-hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, hipStream_t s);
+hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, unsigned long long* publish,
+                                  uint32_t ticket, hipStream_t s);
 hipError_t launch_depth_keys(const FrameParams& fp, GeomState g, uint32_t* keys_out, uint32_t* vals_out, hipStream_t s);
 hipError_t launch_sorted_block_sums(const FrameParams& fp, GeomState g, hipStream_t s);
 hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
 hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
-                       uint32_t* ivals_out, hipStream_t s);
+                       uint32_t* ivals_out, bool key16, hipStream_t s);
 hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningState b, float* dL_dmean2D,
                                  float* dL_dconic, float* dL_dopacity, float* dL_dcolor, hipStream_t s);
 // Stable LSD radix sort of n (u32, u32) pairs on key bits [0, end_bit); buffers ping-pong between
 // (keysA, valsA) and (keysB, valsB), starting in A when start_in_A.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
-                             int n, int end_bit, bool start_in_A, bool is_depth_sort, hipStream_t s);
-hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, int tiles, hipStream_t s);
+                             int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16, hipStream_t s);
+hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, int tiles, bool key16, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, hipStream_t s);
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,

@@ -248,8 +248,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
 // Together with the in-block scan in k_duplicate this is cub::DeviceScan::InclusiveSum
 // (reference rasterizer_impl.cu:270-273).
 // ------------------------------------------------------------------------------------------------
+// `publish` (optional) is a host-mapped, page-locked 8-byte word: the total and the caller's ticket go out
+// in one store, so the host can pick the value up by polling memory instead of waiting for a copy engine
+// and a completion interrupt.
 __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, int nb,
-                                                          uint32_t* __restrict__ total) {
+                                                          uint32_t* __restrict__ total,
+                                                          unsigned long long* __restrict__ publish,
+                                                          uint32_t ticket) {
   __shared__ uint32_t wtot[16];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -269,7 +274,13 @@ __global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__
     if (tid == 1023) carry_s = carry + woff + inc;
     __syncthreads();
   }
-  if (tid == 0) total[0] = carry_s;
+  if (tid == 0) {
+    total[0] = carry_s;
+    if (publish) {
+      __hip_atomic_store(publish, ((unsigned long long)ticket << 32) | carry_s, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -365,9 +376,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_emit_chunks(const FrameParams fp,
   if (end == (uint32_t)R) chunk_first[(R + EMIT_CHUNK - 1) / EMIT_CHUNK] = (uint32_t)i;
 }
 
+template <typename K>
 __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g, const int R,
                                               const uint32_t* __restrict__ chunk_first,
-                                              uint32_t* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out) {
+                                              K* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out) {
   __shared__ uint32_t s_off[EMIT_CHUNK + 2], s_id[EMIT_CHUNK + 1], s_rect[EMIT_CHUNK + 1], s_inv[EMIT_CHUNK + 1];
   const int tid = threadIdx.x;
   const uint32_t c0 = (uint32_t)blockIdx.x * EMIT_CHUNK;
@@ -420,15 +432,20 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
     }
   }
   if (t0 + 8u <= c1) {
-    uint4* ko = reinterpret_cast<uint4*>(tkeys_out + t0);
     uint4* vo = reinterpret_cast<uint4*>(ivals_out + t0);
-    ko[0] = make_uint4(tk[0], tk[1], tk[2], tk[3]);
-    ko[1] = make_uint4(tk[4], tk[5], tk[6], tk[7]);
+    if (sizeof(K) == 2) {  // eight 16-bit tile ids = one 16-byte store
+      *reinterpret_cast<uint4*>(tkeys_out + t0) = make_uint4(tk[0] | (tk[1] << 16), tk[2] | (tk[3] << 16),
+                                                             tk[4] | (tk[5] << 16), tk[6] | (tk[7] << 16));
+    } else {
+      uint4* ko = reinterpret_cast<uint4*>(tkeys_out + t0);
+      ko[0] = make_uint4(tk[0], tk[1], tk[2], tk[3]);
+      ko[1] = make_uint4(tk[4], tk[5], tk[6], tk[7]);
+    }
     vo[0] = make_uint4(iv[0], iv[1], iv[2], iv[3]);
     vo[1] = make_uint4(iv[4], iv[5], iv[6], iv[7]);
   } else {
     for (int k = 0; k < 8 && t0 + (uint32_t)k < c1; k++) {
-      tkeys_out[t0 + k] = tk[k];
+      tkeys_out[t0 + k] = (K)tk[k];
       ivals_out[t0 + k] = iv[k];
     }
   }
@@ -774,9 +791,10 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
   return hipGetLastError();
 }
 
-hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, hipStream_t s) {
+hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, unsigned long long* publish,
+                                  uint32_t ticket, hipStream_t s) {
   ProfScope ps(K_SCAN_BLOCKS, s);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, sums, nb, total);
+  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, sums, nb, total, publish, ticket);
   return hipGetLastError();
 }
 
@@ -803,7 +821,7 @@ hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, hipStream_t
 }
 
 hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
-                       uint32_t* ivals_out, hipStream_t s) {
+                       uint32_t* ivals_out, bool key16, hipStream_t s) {
   if (R <= 0) return hipSuccess;
   {
     ProfScope ps(K_EMIT_CHUNKS, s);
@@ -811,8 +829,12 @@ hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chun
                        chunk_first);
   }
   ProfScope ps(K_EMIT, s);
-  hipLaunchKernelGGL(k_emit, dim3((R + EMIT_CHUNK - 1) / EMIT_CHUNK), dim3(256), 0, s, fp, g, R, chunk_first,
-                     tkeys_out, ivals_out);
+  const dim3 grid((R + EMIT_CHUNK - 1) / EMIT_CHUNK);
+  if (key16)
+    hipLaunchKernelGGL(k_emit<uint16_t>, grid, dim3(256), 0, s, fp, g, R, chunk_first,
+                       reinterpret_cast<uint16_t*>(tkeys_out), ivals_out);
+  else
+    hipLaunchKernelGGL(k_emit<uint32_t>, grid, dim3(256), 0, s, fp, g, R, chunk_first, tkeys_out, ivals_out);
   return hipGetLastError();
 }
 

@@ -64,7 +64,8 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, int lane, in
 
 // Per-tile digit counts with LDS integer atomics (order-independent, so still deterministic): three
 // instructions per key instead of a ballot match; neighbouring keys rarely share a digit in either sort.
-__global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ keys, int n, int shift, int nbits,
+template <typename K>
+__global__ __launch_bounds__(256) void k_sort_hist(const K* __restrict__ keys, int n, int shift, int nbits,
                                                    uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[256];
   const int tid = threadIdx.x;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t* __restrict__ 
 #pragma unroll
   for (int s = 0; s < SORT_TILE / 256; s++) {
     const size_t i = base + (size_t)s * 256 + tid;
-    key[s] = i < (size_t)n ? keys[i] : 0xFFFFFFFFu;
+    key[s] = i < (size_t)n ? (uint32_t)keys[i] : 0u;
   }
 #pragma unroll
   for (int s = 0; s < SORT_TILE / 256; s++) {
@@ -121,16 +122,18 @@ __global__ __launch_bounds__(256) void k_sort_scan_top(uint32_t* __restrict__ ch
   if (lane == 0) digit_total[d] = carry;
 }
 
-__global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* __restrict__ keys_in,
+template <typename K>
+__global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys_in,
                                                       const uint32_t* __restrict__ vals_in,
-                                                      uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                      K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                       int n, int shift, int nbits, const uint32_t* __restrict__ counts,
                                                       const uint32_t* __restrict__ chunk_base,
                                                       const uint32_t* __restrict__ digit_total) {
   __shared__ uint32_t wcnt[4][256];  // per-wave digit counts, then per-wave local write bases
   __shared__ uint32_t gdelta[256];   // global position of local slot p holding digit d = gdelta[d] + p
   __shared__ uint32_t wtot[4];
-  __shared__ uint32_t lkey[SORT_TILE], lval[SORT_TILE];
+  __shared__ K lkey[SORT_TILE];
+  __shared__ uint32_t lval[SORT_TILE];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tile = blockIdx.x;
   const uint32_t mask = (1u << nbits) - 1u;
@@ -144,7 +147,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* __restrict
   for (int s = 0; s < STEPS; s++) {
     const size_t i = base + (size_t)s * 64 + lane;
     const bool valid = i < (size_t)n;
-    key[s] = valid ? keys_in[i] : 0u;
+    key[s] = valid ? (uint32_t)keys_in[i] : 0u;
     val[s] = valid ? vals_in[i] : 0u;
   }
   // pass A: rank of every element among the equal-digit elements of ITS WAVE that precede it
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* __restrict
     if (i < (size_t)n) {
       const uint32_t d = (key[s] >> shift) & mask;
       const uint32_t p = wcnt[w][d] + lrank[s];
-      lkey[p] = key[s];
+      lkey[p] = (K)key[s];
       lval[p] = val[s];
     }
   }
@@ -194,9 +197,9 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* __restrict
   for (int k = 0; k < SORT_TILE / 256; k++) {
     const uint32_t p = (uint32_t)(k * 256 + tid);
     if (p < nvalid) {
-      const uint32_t kk = lkey[p];
+      const uint32_t kk = (uint32_t)lkey[p];
       const uint32_t g = gdelta[(kk >> shift) & mask] + p;
-      keys_out[g] = kk;
+      keys_out[g] = (K)kk;
       vals_out[g] = lval[p];
     }
   }
@@ -204,15 +207,16 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const uint32_t* __restrict
 
 // Replaces identifyTileRanges (reference rasterizer_impl.cu:106-125); ranges must be zeroed first
 // (the reference's cudaMemset at :311).
-__global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict__ keys, int L,
+template <typename K>
+__global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys, int L,
                                                      uint2* __restrict__ ranges) {
   const int idx = blockIdx.x * 256 + threadIdx.x;
   if (idx >= L) return;
-  const uint32_t cur = keys[idx];
+  const uint32_t cur = (uint32_t)keys[idx];
   if (idx == 0) {
     ranges[cur].x = 0;
   } else {
-    const uint32_t prev = keys[idx - 1];
+    const uint32_t prev = (uint32_t)keys[idx - 1];
     if (cur != prev) {
       ranges[prev].y = (uint32_t)idx;
       ranges[cur].x = (uint32_t)idx;
@@ -223,9 +227,9 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const uint32_t* __restrict_
 
 // The pairs start in (keysA, valsA) when start_in_A, else in (keysB, valsB); passes alternate.  The caller
 // picks start_in_A = (passes even) so the result always lands in (keysA, valsA).
-hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
-                             int n, int end_bit, bool start_in_A, bool is_depth_sort, hipStream_t s) {
-  if (n <= 0) return hipSuccess;
+template <typename K>
+static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t* valsB, SortScratch sc, int n,
+                                  int end_bit, bool start_in_A, bool is_depth_sort, hipStream_t s) {
   const int kb = is_depth_sort ? (int)K_DSORT_HIST - (int)K_SORT_HIST : 0;  // profiler ids of this sort
   const int ntiles = (n + SORT_TILE - 1) / SORT_TILE;
   const int nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
@@ -233,14 +237,14 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
   const int nbits = sort_digit_bits(end_bit);
   bool inA = start_in_A;
   for (int p = 0; p < passes; p++) {
-    const uint32_t* kin = inA ? keysA : keysB;
+    const K* kin = inA ? keysA : keysB;
     const uint32_t* vin = inA ? valsA : valsB;
-    uint32_t* kout = inA ? keysB : keysA;
+    K* kout = inA ? keysB : keysA;
     uint32_t* vout = inA ? valsB : valsA;
     const int shift = nbits * p;
     {
       ProfScope ps(K_SORT_HIST + kb, s);
-      hipLaunchKernelGGL(k_sort_hist, dim3(ntiles), dim3(256), 0, s, kin, n, shift, nbits, sc.counts);
+      hipLaunchKernelGGL(k_sort_hist<K>, dim3(ntiles), dim3(256), 0, s, kin, n, shift, nbits, sc.counts);
     }
     {
       ProfScope ps(K_SORT_SCAN_CHUNKS + kb, s);
@@ -252,7 +256,7 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
     }
     {
       ProfScope ps(K_SORT_SCATTER + kb, s);
-      hipLaunchKernelGGL(k_sort_scatter, dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits,
+      hipLaunchKernelGGL(k_sort_scatter<K>, dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits,
                          sc.counts, sc.chunk_sums, sc.digit_base);
     }
     inA = !inA;
@@ -260,12 +264,27 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
   return hipGetLastError();
 }
 
-hipError_t launch_tile_ranges(const uint32_t* keys, int R, uint2* ranges, int tiles, hipStream_t s) {
+// key16: the keys are 16-bit (tile ids of images with <= 65536 tiles): a quarter less traffic per pass; the
+// buffers are the same allocations, viewed as uint16_t.
+hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
+                             int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  if (key16)
+    return sort_pairs_impl<uint16_t>(reinterpret_cast<uint16_t*>(keysA), valsA, reinterpret_cast<uint16_t*>(keysB),
+                                     valsB, sc, n, end_bit, start_in_A, is_depth_sort, s);
+  return sort_pairs_impl<uint32_t>(keysA, valsA, keysB, valsB, sc, n, end_bit, start_in_A, is_depth_sort, s);
+}
+
+hipError_t launch_tile_ranges(const uint32_t* keys, int R, uint2* ranges, int tiles, bool key16, hipStream_t s) {
   hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
   if (e != hipSuccess) return e;
   if (R > 0) {
     ProfScope ps(K_TILE_RANGES, s);
-    hipLaunchKernelGGL(k_tile_ranges, dim3((R + 255) / 256), dim3(256), 0, s, keys, R, ranges);
+    if (key16)
+      hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((R + 255) / 256), dim3(256), 0, s,
+                         reinterpret_cast<const uint16_t*>(keys), R, ranges);
+    else
+      hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((R + 255) / 256), dim3(256), 0, s, keys, R, ranges);
   }
   return hipGetLastError();
 }

@@ -111,8 +111,10 @@ typedef struct gsr_geometry_view {
  * this implementation sorts Gaussians by depth once and instances by tile id only, so it stores the two
  * halves separately (same order, see gs-livm_amd/csrc/radix_sort.hip). */
 typedef struct gsr_binning_view {
-  const uint32_t* tile_ids;       /* [R] sorted tile id per instance; valid until gsr_backward runs */
+  const void* tile_ids;           /* [R] sorted tile id per instance (uint16 or uint32, see tile_id_bytes);
+                                     valid until gsr_backward runs */
   const uint32_t* point_list;     /* [R] sorted Gaussian ids              */
+  int tile_id_bytes;              /* 2 when the image has <= 65536 tiles, else 4 */
 } gsr_binning_view;
 typedef struct gsr_image_view {
   const uint32_t* ranges;         /* [tiles][2]                           */
@@ -122,7 +124,7 @@ typedef struct gsr_image_view {
                                      the tile's maximum = list entries the backward walks */
 } gsr_image_view;
 int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out);
-int gsr_binning_view_of(char* binning_buffer, int R, gsr_binning_view* out);
+int gsr_binning_view_of(char* binning_buffer, int R, int width, int height, gsr_binning_view* out);
 int gsr_image_view_of(char* image_buffer, int width, int height, gsr_image_view* out);
 
 /* getHigherMsb (rasterizer_impl.cu:35-48): number of tile-id bits the sort covers. */
