@@ -22,7 +22,7 @@ class GeometryView(C.Structure):
 
 
 class BinningView(C.Structure):
-    _fields_ = [("tile_ids", C.c_void_p), ("point_list", C.c_void_p), ("tile_id_bytes", C.c_int)]
+    _fields_ = [("point_list", C.c_void_p)]
 
 
 class ImageView(C.Structure):
@@ -34,7 +34,7 @@ _lib = None
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_bytes", "gsr_image_bytes",
            "gsr_binning_bytes", "gsr_geometry_view_of", "gsr_binning_view_of", "gsr_image_view_of",
            "gsr_higher_msb", "gsr_last_error", "gsr_abi_version", "gsr_kernel_count", "gsr_kernel_name",
-           "gsr_profile_enable", "gsr_profile_read", "gsr_activate", "gsr_activate_backward", "gsr_adam_step",
+           "gsr_profile_enable", "gsr_profile_enable_only", "gsr_profile_read", "gsr_activate", "gsr_activate_backward", "gsr_adam_step",
            "gsr_photometric_loss", "gsr_photometric_loss_workspace")
 
 
@@ -63,7 +63,7 @@ def lib():
     L.gsr_image_bytes.restype = sz
     L.gsr_image_bytes.argtypes = [ci, ci]
     L.gsr_geometry_view_of.argtypes = [vp, ci, C.POINTER(GeometryView)]
-    L.gsr_binning_view_of.argtypes = [vp, ci, ci, ci, C.POINTER(BinningView)]
+    L.gsr_binning_view_of.argtypes = [vp, ci, C.POINTER(BinningView)]
     L.gsr_image_view_of.argtypes = [vp, ci, ci, C.POINTER(ImageView)]
     L.gsr_higher_msb.restype = C.c_uint32
     L.gsr_higher_msb.argtypes = [C.c_uint32]
@@ -73,6 +73,7 @@ def lib():
     L.gsr_kernel_name.restype = C.c_char_p
     L.gsr_kernel_name.argtypes = [ci]
     L.gsr_profile_enable.argtypes = [ci]
+    L.gsr_profile_enable_only.argtypes = [C.POINTER(ci), ci]
     L.gsr_profile_read.restype = ci
     L.gsr_profile_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(ci)]
     L.gsr_activate.restype = ci
@@ -142,7 +143,7 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
     out_color = torch.empty((3, H, W), **f32)
     out_depth = torch.empty((1, H, W), **f32)
     out_acc = torch.empty((1, H, W), **f32)
-    radii = torch.zeros((P,), dtype=torch.int32, device=dev)
+    radii = torch.empty((P,), dtype=torch.int32, device=dev)  # the library writes every entry
     gb, bb, ib = _Blob(dev), _Blob(dev), _Blob(dev)
     M = int(sh.size(1)) if (sh is not None and sh.numel() != 0) else 0
     L = lib()
@@ -233,11 +234,11 @@ def state_views(geomBuffer, binningBuffer, imageBuffer, P, R, W, H):
                    n_contrib=_sub(imageBuffer, iv.n_contrib, W * H, torch.int32).view(H, W),
                    quad_last=_sub(imageBuffer, iv.quad_last, T * 4, torch.int32).view(T, 4))
         if R:
-            _check(L.gsr_binning_view_of(_ptr(binningBuffer), R, W, H, C.byref(bv)))
-            if bv.tile_id_bytes == 2:  # uint16 tile ids (read as int16, then widened without sign)
-                tile_ids = _sub(binningBuffer, bv.tile_ids, R, torch.int16).int() & 0xFFFF
-            else:
-                tile_ids = _sub(binningBuffer, bv.tile_ids, R, torch.int32)
+            _check(L.gsr_binning_view_of(_ptr(binningBuffer), R, C.byref(bv)))
+            # tile of instance i = the tile whose range contains i (the last sort pass marks ranges instead of
+            # storing the sorted tile ids)
+            rg = out["ranges"].long()
+            tile_ids = torch.repeat_interleave(torch.arange(T, device=rg.device), rg[:, 1] - rg[:, 0])
             point_list = _sub(binningBuffer, bv.point_list, R, torch.int32)
             # the reference's 64-bit sorted keys, recomposed: (tile << 32) | bits(depth of the instance's Gaussian)
             dbits = out["depths"].view(torch.int32)[point_list.long()].long() & 0xFFFFFFFF
@@ -245,9 +246,16 @@ def state_views(geomBuffer, binningBuffer, imageBuffer, P, R, W, H):
     return out
 
 
-def profile_enable(on=True):
-    """Start / stop recording a hipEvent pair around every kernel launch (bench.py's roofline line)."""
-    _check(lib().gsr_profile_enable(int(bool(on))))
+def profile_enable(on=True, only=None):
+    """Start / stop recording a hipEvent pair around every kernel launch (bench.py's roofline line).
+    `only`: iterable of kernel names -- record just those (each recorded launch costs a few us of GPU idle)."""
+    L = lib()
+    if on and only is not None:
+        names = [L.gsr_kernel_name(i).decode() for i in range(L.gsr_kernel_count())]
+        ids = [names.index(k) for k in only]
+        _check(L.gsr_profile_enable_only((C.c_int * len(ids))(*ids), len(ids)))
+    else:
+        _check(L.gsr_profile_enable(int(bool(on))))
 
 
 def profile_read():

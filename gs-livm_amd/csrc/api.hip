@@ -41,6 +41,7 @@ static int fail(int code, const char* fmt, ...) {
 // ---- optional event profiler -------------------------------------------------------------------
 namespace gsr {
 bool g_prof_on = false;
+unsigned long long g_prof_mask = ~0ull;
 static std::vector<hipEvent_t> g_ev;  // pool: [2*i] start, [2*i+1] stop
 static std::vector<int> g_ev_id;
 static size_t g_ev_used = 0;
@@ -71,6 +72,19 @@ const char* gsr_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernel
 int gsr_profile_enable(int on) {
   if (on) g_ev_used = 0;  // a fresh recording; disabling keeps what was recorded for gsr_profile_read
   g_prof_on = on != 0;
+  g_prof_mask = ~0ull;
+  return GSR_OK;
+}
+int gsr_profile_enable_only(const int* kernel_ids, int n) {
+  if (!kernel_ids && n > 0) return fail(GSR_ERR_INVALID_ARGUMENT, "null kernel id list");
+  unsigned long long m = 0;
+  for (int i = 0; i < n; i++) {
+    if (kernel_ids[i] < 0 || kernel_ids[i] >= K_COUNT) return fail(GSR_ERR_INVALID_ARGUMENT, "bad kernel id");
+    m |= 1ull << kernel_ids[i];
+  }
+  g_ev_used = 0;
+  g_prof_mask = m;
+  g_prof_on = true;
   return GSR_OK;
 }
 int gsr_profile_read(int max_ids, double* total_ms, int* launches) {
@@ -199,7 +213,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
                           /*is_depth_sort=*/true, /*key16=*/false, stream));
   STAGE(launch_sorted_block_sums(fp, g, stream));
   STAGE(launch_scan_block_sums(g.block_sums2, nb, g.total + 1, nullptr, 0, stream));
-  STAGE(launch_sorted_offsets(fp, g, stream));
+  STAGE(launch_sorted_offsets(fp, g, im.ranges, stream));
   uint32_t R_host = 0;
   const std::chrono::steady_clock::time_point t_enqueued = std::chrono::steady_clock::now();
   {
@@ -243,10 +257,10 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
   const bool key16 = tiles <= 65536;  // tile ids fit 16 bits for every image up to 4096 x 4096
   STAGE(launch_emit(fp, g, R, b.chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB,
-                    key16, stream));
+                    b.inst_flag, key16, stream));
   STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, R, tile_bits, start_in_A,
                           /*is_depth_sort=*/false, key16, stream));
-  STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, tiles, key16, stream));
+  STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, key16, stream));
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
   return R;
 }
@@ -277,9 +291,8 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
   const float* cov3D_used = cov3D_precomp ? cov3D_precomp : g.cov3D;  // rasterizer_impl.cu:427
 
   if (R > 0) {
-    STAGE(hipMemsetAsync(b.inst_flag, 0, (size_t)R, stream));
-    STAGE(hipMemsetAsync(g.touched, 0, (size_t)P, stream));
-    STAGE(hipMemsetAsync(g.total + 2, 0, sizeof(uint32_t), stream));
+    // inst_flag, touched and total[2] are zero here: the forward initialises them and the gather kernels
+    // below clear what the blend backward sets, so the same blobs can be differentiated again.
     STAGE(launch_blend_backward(fp, g, b, im, background, dL_dpix, dL_dacc, stream));
     STAGE(launch_gather_records(fp, g, b, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, stream));
   }
@@ -380,12 +393,9 @@ int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out) {
   return GSR_OK;
 }
 
-int gsr_binning_view_of(char* binning_buffer, int R, int width, int height, gsr_binning_view* out) {
-  if (!binning_buffer || !out || R < 0 || width <= 0 || height <= 0)
-    return fail(GSR_ERR_INVALID_ARGUMENT, "bad argument");
+int gsr_binning_view_of(char* binning_buffer, int R, gsr_binning_view* out) {
+  if (!binning_buffer || !out || R < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad argument");
   BinningState b = BinningState::carve(binning_buffer, (size_t)R);
-  out->tile_ids = b.tkeysA;
-  out->tile_id_bytes = ((width + TILE - 1) / TILE) * ((height + TILE - 1) / TILE) <= 65536 ? 2 : 4;
   out->point_list = b.point_list;
   return GSR_OK;
 }

@@ -182,16 +182,16 @@ hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, unsig
                                   uint32_t ticket, hipStream_t s);
 hipError_t launch_depth_keys(const FrameParams& fp, GeomState g, uint32_t* keys_out, uint32_t* vals_out, hipStream_t s);
 hipError_t launch_sorted_block_sums(const FrameParams& fp, GeomState g, hipStream_t s);
-hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
+hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, uint2* ranges, hipStream_t s);
 hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
-                       uint32_t* ivals_out, bool key16, hipStream_t s);
+                       uint32_t* ivals_out, uint8_t* inst_flag, bool key16, hipStream_t s);
 hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningState b, float* dL_dmean2D,
                                  float* dL_dconic, float* dL_dopacity, float* dL_dcolor, hipStream_t s);
 // Stable LSD radix sort of n (u32, u32) pairs on key bits [0, end_bit); buffers ping-pong between
 // (keysA, valsA) and (keysB, valsB), starting in A when start_in_A.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
                              int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16, hipStream_t s);
-hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, int tiles, bool key16, hipStream_t s);
+hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, bool key16, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, hipStream_t s);
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
@@ -234,10 +234,11 @@ enum KernelId {
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);
 extern bool g_prof_on;
+extern unsigned long long g_prof_mask;  // bit i: kernel id i is recorded
 struct ProfScope {  // records a start/stop event pair around the launches in its scope while profiling is on
   hipStream_t s;
   bool on;
-  ProfScope(int id, hipStream_t st) : s(st), on(g_prof_on) { if (on) prof_begin(id, s); }
+  ProfScope(int id, hipStream_t st) : s(st), on(g_prof_on && ((g_prof_mask >> id) & 1ull)) { if (on) prof_begin(id, s); }
   ~ProfScope() { if (on) prof_end(s); }
 };
 

@@ -234,6 +234,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     if (radii_out) radii_out[idx] = radius;
     g.tiles_touched[idx] = tiles;
     g.gpack[idx] = make_uint2(tiles, tiles ? rect_packed : 0u);
+    g.touched[idx] = 0;  // backward bookkeeping starts clean (the backward clears what it sets)
+    if (idx == 0) g.total[2] = 0u;
   }
   // per-block sum of tiles_touched -> block_sums[blockIdx.x]
   __shared__ uint32_t wsum[PRE_BLOCK / 64];
@@ -343,9 +345,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_sorted_block_sums(const FramePara
 // workgroup is constant however skewed the tile counts are (the nearest Gaussians own >1000 tiles
 // each and sit next to each other in depth order), and all stores are coalesced.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PRE_BLOCK) void k_sorted_offsets(const FrameParams fp, GeomState g) {
+__global__ __launch_bounds__(PRE_BLOCK) void k_sorted_offsets(const FrameParams fp, GeomState g,
+                                                              uint2* __restrict__ ranges) {
   __shared__ uint32_t wtot[PRE_BLOCK / 64];
   const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
+  // side job: (0, 0) for the tiles no instance lands in (the reference's cudaMemset, rasterizer_impl.cu:311)
+  for (int t = i; t < fp.gx * fp.gy; t += gridDim.x * PRE_BLOCK) ranges[t] = make_uint2(0u, 0u);
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const uint32_t n = i < fp.P ? g.sn[i] : 0u;
   const uint32_t inc = wave_incl_scan_u32(n, lane);
@@ -379,7 +384,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_emit_chunks(const FrameParams fp,
 template <typename K>
 __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g, const int R,
                                               const uint32_t* __restrict__ chunk_first,
-                                              K* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out) {
+                                              K* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out,
+                                              uint8_t* __restrict__ inst_flag) {
   __shared__ uint32_t s_off[EMIT_CHUNK + 2], s_id[EMIT_CHUNK + 1], s_rect[EMIT_CHUNK + 1], s_inv[EMIT_CHUNK + 1];
   const int tid = threadIdx.x;
   const uint32_t c0 = (uint32_t)blockIdx.x * EMIT_CHUNK;
@@ -443,10 +449,12 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
     }
     vo[0] = make_uint4(iv[0], iv[1], iv[2], iv[3]);
     vo[1] = make_uint4(iv[4], iv[5], iv[6], iv[7]);
+    *reinterpret_cast<uint2*>(inst_flag + t0) = make_uint2(0u, 0u);  // no gradient record in these slots yet
   } else {
     for (int k = 0; k < 8 && t0 + (uint32_t)k < c1; k++) {
       tkeys_out[t0 + k] = (K)tk[k];
       ivals_out[t0 + k] = iv[k];
+      inst_flag[t0 + k] = 0;
     }
   }
 }
@@ -460,18 +468,40 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
 // bitwise reproducible because each sum has a fixed association order.  Replaces the 9 atomicAdds per
 // (pixel, Gaussian) of the reference (backward.cu:565, 591-600).
 // ------------------------------------------------------------------------------------------------
+// Every thread owns sixteen flag bytes (one 16-byte load) and a workgroup appends its ids with ONE atomicAdd
+// (same-address atomics retire one at a time in L2: a few hundred of them, not one per wave).  The list order
+// is arbitrary; every Gaussian is gathered independently, so the results do not depend on it.
 __global__ __launch_bounds__(PRE_BLOCK) void k_compact_touched(const int P, const uint8_t* __restrict__ touched,
                                                                uint32_t* __restrict__ list,
                                                                uint32_t* __restrict__ count) {
-  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  const int lane = threadIdx.x & 63;
-  const bool t = idx < P && touched[idx];
-  const uint64_t m = __ballot(t);
-  if (m == 0ull) return;
-  uint32_t base = 0;
-  if (lane == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
-  base = __shfl(base, 0, 64);
-  if (t) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)idx;
+  __shared__ uint32_t wtot[PRE_BLOCK / 64];
+  __shared__ uint32_t wg_base;
+  const int idx0 = (blockIdx.x * PRE_BLOCK + threadIdx.x) * 16;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  uint32_t f[4] = {0u, 0u, 0u, 0u};
+  if (idx0 + 15 < P) {
+    const uint4 v = *reinterpret_cast<const uint4*>(touched + idx0);
+    f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+  } else {
+    for (int k = 0; k < 16 && idx0 + k < P; k++) f[k >> 2] |= (uint32_t)touched[idx0 + k] << (8 * (k & 3));
+  }
+  uint32_t c = 0;
+#pragma unroll
+  for (int k = 0; k < 16; k++) c += ((f[k >> 2] >> (8 * (k & 3))) & 0xFFu) ? 1u : 0u;
+  const uint32_t inc = wave_incl_scan_u32(c, lane);
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t tot = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+    wg_base = tot ? atomicAdd(count, tot) : 0u;
+  }
+  __syncthreads();
+  if (!c) return;
+  uint32_t base = wg_base + inc - c;
+  for (int k = 0; k < w; k++) base += wtot[k];
+#pragma unroll
+  for (int k = 0; k < 16; k++)
+    if ((f[k >> 2] >> (8 * (k & 3))) & 0xFFu) list[base++] = (uint32_t)(idx0 + k);
 }
 
 template <int CTRL, int ROW_MASK>
@@ -495,7 +525,7 @@ __device__ __forceinline__ void swap_add16_(float& a, float& b) {
 }
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
-    GeomState g, const float4* __restrict__ grad_inst, const uint8_t* __restrict__ inst_flag,
+    GeomState g, const float4* __restrict__ grad_inst, uint8_t* __restrict__ inst_flag,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dcolor) {
   const int lane = threadIdx.x & 63;
@@ -518,6 +548,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
       for (int j = 0; j < 4; j++) {
         if (f[j]) {
           const size_t slot = first + base + 64 * j + lane;
+          inst_flag[slot] = 0;  // consumed: the blobs are clean for another backward
           const float4 a = grad_inst[slot * GRAD_F4 + 0];
           const float4 b = grad_inst[slot * GRAD_F4 + 1];
           const float4 c = grad_inst[slot * GRAD_F4 + 2];
@@ -569,7 +600,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
   const bool vis = radii[idx] > 0;
   // ---- gather-sum of the instance records ----
   float gcol0 = 0, gcol1 = 0, gcol2 = 0, gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
-  if (vis && g.touched[idx]) {  // sums left by k_gather_records; everything else has no record at all
+  if (idx == 0) g.total[2] = 0u;  // the touched list has been consumed (k_gather_records ran before this kernel)
+  const bool was_touched = g.touched[idx] != 0;
+  if (was_touched) g.touched[idx] = 0;  // leave the blobs clean for another backward over them
+  if (vis && was_touched) {  // sums left by k_gather_records; everything else has no record at all
     gcol0 = dL_dcolor[3 * idx]; gcol1 = dL_dcolor[3 * idx + 1]; gcol2 = dL_dcolor[3 * idx + 2];
     gmx = dL_dmean2D[3 * idx]; gmy = dL_dmean2D[3 * idx + 1];
     gca = dL_dconic[4 * idx]; gcb = dL_dconic[4 * idx + 1]; gcc = dL_dconic[4 * idx + 3];
@@ -813,15 +847,15 @@ hipError_t launch_sorted_block_sums(const FrameParams& fp, GeomState g, hipStrea
   return hipGetLastError();
 }
 
-hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, hipStream_t s) {
+hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, uint2* ranges, hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps(K_SORTED_OFFSETS, s);
-  hipLaunchKernelGGL(k_sorted_offsets, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g);
+  hipLaunchKernelGGL(k_sorted_offsets, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, ranges);
   return hipGetLastError();
 }
 
 hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
-                       uint32_t* ivals_out, bool key16, hipStream_t s) {
+                       uint32_t* ivals_out, uint8_t* inst_flag, bool key16, hipStream_t s) {
   if (R <= 0) return hipSuccess;
   {
     ProfScope ps(K_EMIT_CHUNKS, s);
@@ -832,9 +866,10 @@ hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chun
   const dim3 grid((R + EMIT_CHUNK - 1) / EMIT_CHUNK);
   if (key16)
     hipLaunchKernelGGL(k_emit<uint16_t>, grid, dim3(256), 0, s, fp, g, R, chunk_first,
-                       reinterpret_cast<uint16_t*>(tkeys_out), ivals_out);
+                       reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag);
   else
-    hipLaunchKernelGGL(k_emit<uint32_t>, grid, dim3(256), 0, s, fp, g, R, chunk_first, tkeys_out, ivals_out);
+    hipLaunchKernelGGL(k_emit<uint32_t>, grid, dim3(256), 0, s, fp, g, R, chunk_first, tkeys_out, ivals_out,
+                       inst_flag);
   return hipGetLastError();
 }
 
@@ -843,7 +878,8 @@ hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningStat
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   {
     ProfScope ps(K_COMPACT_TOUCHED, s);
-    hipLaunchKernelGGL(k_compact_touched, dim3(nb), dim3(PRE_BLOCK), 0, s, fp.P, g.touched, g.tlist, g.total + 2);
+    hipLaunchKernelGGL(k_compact_touched, dim3((nb + 15) / 16), dim3(PRE_BLOCK), 0, s, fp.P, g.touched, g.tlist,
+                       g.total + 2);
   }
   {
     ProfScope ps(K_GATHER_RECORDS, s);

@@ -205,26 +205,6 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys
   }
 }
 
-// Replaces identifyTileRanges (reference rasterizer_impl.cu:106-125); ranges must be zeroed first
-// (the reference's cudaMemset at :311).
-template <typename K>
-__global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys, int L,
-                                                     uint2* __restrict__ ranges) {
-  const int idx = blockIdx.x * 256 + threadIdx.x;
-  if (idx >= L) return;
-  const uint32_t cur = (uint32_t)keys[idx];
-  if (idx == 0) {
-    ranges[cur].x = 0;
-  } else {
-    const uint32_t prev = (uint32_t)keys[idx - 1];
-    if (cur != prev) {
-      ranges[prev].y = (uint32_t)idx;
-      ranges[cur].x = (uint32_t)idx;
-    }
-  }
-  if (idx == L - 1) ranges[cur].y = (uint32_t)L;
-}
-
 // The pairs start in (keysA, valsA) when start_in_A, else in (keysB, valsB); passes alternate.  The caller
 // picks start_in_A = (passes even) so the result always lands in (keysA, valsA).
 template <typename K>
@@ -275,17 +255,47 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
   return sort_pairs_impl<uint32_t>(keysA, valsA, keysB, valsB, sc, n, end_bit, start_in_A, is_depth_sort, s);
 }
 
-hipError_t launch_tile_ranges(const uint32_t* keys, int R, uint2* ranges, int tiles, bool key16, hipStream_t s) {
-  hipError_t e = hipMemsetAsync(ranges, 0, sizeof(uint2) * (size_t)tiles, s);
-  if (e != hipSuccess) return e;
-  if (R > 0) {
-    ProfScope ps(K_TILE_RANGES, s);
-    if (key16)
-      hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((R + 255) / 256), dim3(256), 0, s,
-                         reinterpret_cast<const uint16_t*>(keys), R, ranges);
-    else
-      hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((R + 255) / 256), dim3(256), 0, s, keys, R, ranges);
+// Replaces identifyTileRanges (reference rasterizer_impl.cu:106-125); ranges must be zero beforehand (the
+// reference's cudaMemset at :311 -- here a side job of k_sorted_offsets).  Every thread owns 16 bytes of sorted
+// keys (8 x u16 or 4 x u32) plus the key before them, so the pass over the keys runs at streaming rate.
+template <typename K>
+__global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys, int L, uint2* __restrict__ ranges) {
+  constexpr int PER = 16 / (int)sizeof(K);
+  const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * PER;
+  if (i0 >= (size_t)L) return;
+  uint32_t k[PER];
+  if (i0 + PER <= (size_t)L) {
+    const uint4 v = *reinterpret_cast<const uint4*>(keys + i0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < PER; j++) k[j] = sizeof(K) == 2 ? (w[j >> 1] >> (16 * (j & 1))) & 0xFFFFu : w[j];
+  } else {
+#pragma unroll
+    for (int j = 0; j < PER; j++) k[j] = i0 + j < (size_t)L ? (uint32_t)keys[i0 + j] : 0u;
   }
+  uint32_t prev = i0 ? (uint32_t)keys[i0 - 1] : 0xFFFFFFFFu;  // no tile has this id
+#pragma unroll
+  for (int j = 0; j < PER; j++) {
+    const size_t i = i0 + j;
+    if (i < (size_t)L) {
+      if (k[j] != prev) {
+        if (i) ranges[prev].y = (uint32_t)i;
+        ranges[k[j]].x = (uint32_t)i;
+      }
+      if (i == (size_t)L - 1) ranges[k[j]].y = (uint32_t)L;
+      prev = k[j];
+    }
+  }
+}
+
+hipError_t launch_tile_ranges(const uint32_t* keys, int R, uint2* ranges, bool key16, hipStream_t s) {
+  if (R <= 0) return hipSuccess;
+  ProfScope ps(K_TILE_RANGES, s);
+  if (key16)
+    hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((R + 2047) / 2048), dim3(256), 0, s,
+                       reinterpret_cast<const uint16_t*>(keys), R, ranges);
+  else
+    hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((R + 1023) / 1024), dim3(256), 0, s, keys, R, ranges);
   return hipGetLastError();
 }
 

@@ -67,7 +67,8 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
   torch::Tensor out_color = torch::empty({3, H, W}, float_opts);
   torch::Tensor out_depth = torch::empty({1, H, W}, float_opts);
   torch::Tensor out_acc = torch::empty({1, H, W}, float_opts);
-  torch::Tensor radii = torch::full({P}, 0, means3D.options().dtype(torch::kInt32));
+  torch::Tensor radii = P ? torch::empty({P}, means3D.options().dtype(torch::kInt32))  // every entry is written
+                          : torch::zeros({0}, means3D.options().dtype(torch::kInt32));
   auto byte_opts = means3D.options().dtype(torch::kByte);
   torch::Tensor geomBuffer = torch::empty({0}, byte_opts);
   torch::Tensor binningBuffer = torch::empty({0}, byte_opts);
@@ -195,6 +196,7 @@ class _RasterizeGaussians : public torch::autograd::Function<_RasterizeGaussians
     ctx->saved_data["camera_center"] = camera_center;
     ctx->saved_data["prefiltered"] = prefiltered_val;
     ctx->mark_non_differentiable({radii});
+    ctx->set_materialize_grads(false);  // no zero images for the outputs nobody differentiates (depth)
     return {color, radii, out_depth, out_acc};
   }
 

@@ -44,6 +44,7 @@ class _RasterizeGaussians(torch.autograd.Function):
         ctx.save_for_backward(colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geom, binning,
                               img)
         ctx.mark_non_differentiable(radii)
+        ctx.set_materialize_grads(False)  # no zero image for the depth output nobody differentiates
         return color, radii, depth, acc
 
     @staticmethod

@@ -107,14 +107,13 @@ typedef struct gsr_geometry_view {
   const uint8_t* clamped;         /* [P] bit0..2 = r,g,b clamp flags      */
   const uint32_t* depth_order;    /* [P] Gaussian ids by (depth bits, id); culled Gaussians last */
 } gsr_geometry_view;
-/* The reference's 64-bit sorted key of instance i is ((uint64)tile_ids[i] << 32) | bits(depths[point_list[i]]);
- * this implementation sorts Gaussians by depth once and instances by tile id only, so it stores the two
- * halves separately (same order, see gs-livm_amd/csrc/radix_sort.hip). */
+/* The reference's 64-bit sorted key of instance i is ((uint64)tile << 32) | bits(depths[point_list[i]]) with
+ * tile = the tile whose range [ranges[tile][0], ranges[tile][1]) contains i: this implementation sorts the
+ * Gaussians by depth once and the instances by a 16- or 32-bit tile id only (gs-livm_amd/csrc/radix_sort.hip);
+ * the sorted tile ids are scratch (overwritten by the backward), so the view exposes point_list and the keys
+ * are implied by ranges + point_list. */
 typedef struct gsr_binning_view {
-  const void* tile_ids;           /* [R] sorted tile id per instance (uint16 or uint32, see tile_id_bytes);
-                                     valid until gsr_backward runs */
   const uint32_t* point_list;     /* [R] sorted Gaussian ids              */
-  int tile_id_bytes;              /* 2 when the image has <= 65536 tiles, else 4 */
 } gsr_binning_view;
 typedef struct gsr_image_view {
   const uint32_t* ranges;         /* [tiles][2]                           */
@@ -124,7 +123,7 @@ typedef struct gsr_image_view {
                                      the tile's maximum = list entries the backward walks */
 } gsr_image_view;
 int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out);
-int gsr_binning_view_of(char* binning_buffer, int R, int width, int height, gsr_binning_view* out);
+int gsr_binning_view_of(char* binning_buffer, int R, gsr_binning_view* out);
 int gsr_image_view_of(char* image_buffer, int width, int height, gsr_image_view* out);
 
 /* getHigherMsb (rasterizer_impl.cu:35-48): number of tile-id bits the sort covers. */
@@ -173,6 +172,9 @@ int gsr_photometric_loss(int channels, int height, int width, const float* img, 
 int gsr_kernel_count(void);
 const char* gsr_kernel_name(int kernel_id);
 int gsr_profile_enable(int on);
+/* like gsr_profile_enable(1), but records only the listed kernel ids: an event pair costs a few microseconds
+ * of GPU idle time per launch, so a timed run should carry events for the kernel under study only. */
+int gsr_profile_enable_only(const int* kernel_ids, int n);
 int gsr_profile_read(int max_ids, double* total_ms, int* launches);
 
 const char* gsr_last_error(void);

@@ -429,6 +429,9 @@ def test_c3_determinism_and_backward_linearity(c3, gpu_device):
         lin = 2.0 * A[k].astype(np.float64) - 3.0 * B[k].astype(np.float64)
         scale = np.abs(lin).max() + 1e-30
         assert np.abs(Cc[k] - lin).max() <= 2e-4 * scale, k
+    A3 = hip_backward(sc, t, fwd, g1c, g1a, dev, debug=False)               # 4th backward over the same blobs:
+    for k in A:                                                             # the bookkeeping flags were left clean
+        assert np.array_equal(A[k], A3[k]), k
     vis = fwd[4].cpu().numpy() > 0
     assert not A["dL_dmeans3D"][~vis].any() and np.isfinite(A["dL_dmeans3D"]).all()
 
