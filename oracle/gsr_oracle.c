@@ -207,6 +207,55 @@ void gsro_free(gsro_frame* f) {
   free(f);
 }
 
+/* ---- NOT reference behaviour: the product's tile culling, restated so its integer stages can be checked ----
+ * With g_tight != 0 (gsro_set_tight; default 0 = the reference's rectangles) a Gaussian's tile rectangle is
+ * cut down to the tiles overlapped by the axis-aligned box that contains every pixel with
+ * alpha = op * exp(power) >= 1/255 (gs-livm_amd/csrc/preprocess.hip, k_preprocess).  Instances outside that box
+ * are skipped pixel by pixel by the reference (forward.cu:343-345), so colour/depth/acc and every gradient
+ * are identical in both modes (tests/test_oracle.py checks that bit for bit); tiles_touched, point_offsets,
+ * the sorted lists, ranges and n_contrib are the ones that differ.  Pure +,*,/ arithmetic: -ffp-contract=off
+ * here and in preprocess.hip make it bit-identical on both sides. */
+static int g_tight = 0;
+void gsro_set_tight(int on) { g_tight = on != 0; }
+int gsro_get_tight(void) { return g_tight; }
+
+static float ln_upper(float x) {
+  uint32_t b;
+  memcpy(&b, &x, 4);
+  int e = (int)(b >> 23) - 127;
+  uint32_t mb = (b & 0x007FFFFFu) | 0x3F800000u;
+  float m;
+  memcpy(&m, &mb, 4);
+  float t = (m - 1.0f) / (m + 1.0f);
+  float t2 = t * t;
+  float s = t * (2.0f + t2 * (0.6666667f + t2 * 0.4f));
+  return (float)e * 0.6931472f + s + 3e-4f;
+}
+
+/* narrows [x0,x1) x [y0,y1); an empty result has x1 <= x0 or y1 <= y0 */
+static void tighten_rect(float px, float py, const float conic[3], float op, int* x0, int* y0, int* x1, int* y1) {
+  float hx, hy;
+  if (op < 1.0f / 255.0f) {
+    *x1 = *x0;
+    return;
+  }
+  float tau = ln_upper(255.0f * op) * 1.01f + 0.02f;
+  float dc = conic[0] * conic[2] - conic[1] * conic[1];
+  if (!(conic[0] > 0.0f && conic[2] > 0.0f && dc > 0.0f)) return; /* indefinite conic: no culling */
+  hx = sqrtf(2.0f * tau * conic[2] / dc) + 0.05f;
+  hy = sqrtf(2.0f * tau * conic[0] / dc) + 0.05f;
+  if (!(hx < 1e6f)) return;
+  const float lim = 1e6f;
+  int bx0 = (int)ceilf(fmaxf_(-lim, fminf_(lim, (px - hx - 15.0f) * 0.0625f)));
+  int bx1 = (int)floorf(fmaxf_(-lim, fminf_(lim, (px + hx) * 0.0625f))) + 1;
+  int by0 = (int)ceilf(fmaxf_(-lim, fminf_(lim, (py - hy - 15.0f) * 0.0625f)));
+  int by1 = (int)floorf(fmaxf_(-lim, fminf_(lim, (py + hy) * 0.0625f))) + 1;
+  if (bx0 > *x0) *x0 = bx0;
+  if (bx1 < *x1) *x1 = bx1;
+  if (by0 > *y0) *y0 = by0;
+  if (by1 < *y1) *y1 = by1;
+}
+
 /* forward.cu:179-286 (preprocessCUDA), one Gaussian. */
 static void preprocess_one(gsro_frame* f, int idx, const float* means3D, const float* scales, float mod,
                            const float* rotations, const float* opacities, const float* shs,
@@ -258,7 +307,12 @@ static void preprocess_one(gsro_frame* f, int idx, const float* means3D, const f
   f->conic_opacity[4 * idx + 1] = conic[1];
   f->conic_opacity[4 * idx + 2] = conic[2];
   f->conic_opacity[4 * idx + 3] = opacities[idx];
-  f->tiles_touched[idx] = (uint32_t)((y1 - y0) * (x1 - x0));
+  if (g_tight) {
+    tighten_rect(pix[0], pix[1], conic, opacities[idx], &x0, &y0, &x1, &y1);
+    f->tiles_touched[idx] = (x1 > x0 && y1 > y0) ? (uint32_t)((y1 - y0) * (x1 - x0)) : 0u;
+  } else {
+    f->tiles_touched[idx] = (uint32_t)((y1 - y0) * (x1 - x0));
+  }
 }
 
 /* Stable LSD radix sort of (u64 key, u32 value) pairs: the semantics of
@@ -397,6 +451,11 @@ gsro_frame* gsro_forward(int P, int D, int M, const float* background, int W, in
     uint32_t off = i == 0 ? 0 : f->point_offsets[i - 1];
     int x0, y0, x1, y1;
     tile_rect(f->means2D[2 * i], f->means2D[2 * i + 1], f->radii[i], f->gx, f->gy, &x0, &y0, &x1, &y1);
+    if (g_tight) {
+      if (!f->tiles_touched[i]) continue;
+      tighten_rect(f->means2D[2 * i], f->means2D[2 * i + 1], f->conic_opacity + 4 * i, f->conic_opacity[4 * i + 3],
+                   &x0, &y0, &x1, &y1);
+    }
     uint32_t dbits;
     memcpy(&dbits, &f->depths[i], 4);
     for (int y = y0; y < y1; y++)

@@ -46,6 +46,21 @@ def make(name):
         out["fw_" + k] = getattr(fr, k)
     for k, v in g.items():
         out["bw_" + k] = v
+    # integer stages under the product's tile culling (oracle tight mode): same images/gradients, shorter lists
+    ft = O.forward(sc, tight=True)
+    for k in ("out_color", "out_depth", "out_acc", "final_T", "radii"):
+        assert np.array_equal(getattr(ft, k), getattr(fr, k)), k
+    gt = O.backward(ft, sc, dcol, dacc)
+    assert all(np.array_equal(gt[k], g[k]) for k in g)
+    out["meta_tight"] = np.array([ft.R], np.int64)
+    for k in ("tiles_touched", "point_offsets", "keys", "point_list", "ranges", "n_contrib"):
+        out["tw_" + k] = getattr(ft, k)
+    path = os.path.join(HERE, name + ".npz")
+    if os.path.exists(path):  # the reference-mode vectors are pinned: regenerating must not change them
+        old = np.load(path)
+        for k in old.files:
+            if k in out and not k.startswith("tw_") and k != "meta_tight":
+                assert np.array_equal(old[k], out[k]), "fixture field changed: " + k
     np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
     print(name, "R =", fr.R, "visible =", int((fr.radii > 0).sum()))
 

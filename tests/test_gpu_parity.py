@@ -3,7 +3,10 @@ the CPU oracle on the same seeded inputs, against the committed golden vectors, 
 BASELINE.json's full sizes -- through size-independent properties.
 
 Tolerances (BASELINE.json north_star): integer / index results bit-exact (radii, tile counts,
-offsets, sort keys, sorted Gaussian ids, tile ranges); colour / depth / silhouette <= 1e-4 abs;
+offsets, sort keys, sorted Gaussian ids, tile ranges) -- radii against the reference's definition, the
+per-tile lists against the oracle's `tight` mode, which applies the product's exact-conservative tile
+culling (oracle/gsr_oracle.c, tighten_rect; tests/test_oracle.py proves on the CPU that it leaves every image
+and gradient bit-identical to the reference's rectangles); colour / depth / silhouette <= 1e-4 abs;
 gradients |d| <= 1e-5 * max|g| + 1e-4 * |g_row|_inf (f32 summation order differs; SURVEY.md Appendix B;
 see helpers.grad_close).
 
@@ -100,7 +103,11 @@ SCENES = [  # P, W, H, seed, D
 @pytest.mark.parametrize("P,W,H,seed,D", SCENES)
 def test_forward_backward_parity(P, W, H, seed, D, gpu_device):
     sc = S.make_scene(P, W, H, seed, sh_degree=D)
-    fr = O.forward(sc)
+    fr = O.forward(sc, tight=True)   # integer stages with the product's culled tile rectangles
+    fr_ref = O.forward(sc)           # the reference's rectangles: same radii, images and fragile map bit for bit
+    for k in ("radii", "out_color", "out_depth", "out_acc", "final_T", "fragile"):
+        assert np.array_equal(getattr(fr, k), getattr(fr_ref, k)), k
+    assert (fr.tiles_touched <= fr_ref.tiles_touched).all()
     t, fwd = hip_forward(sc, gpu_device)
     check_forward(sc, fr, fwd, gpu_device)
     dcol, dacc = masked_grads(W, H, seed, fr.fragile)
@@ -130,6 +137,10 @@ def test_against_committed_golden_vectors(name, gpu_device):
     for k in z.files:
         if k.startswith("fw_"):
             setattr(fr, k[3:], z[k])
+    for k in z.files:  # integer stages with the product's culled tile rectangles (oracle tight mode)
+        if k.startswith("tw_"):
+            setattr(fr, k[3:], z[k])
+    fr.R = int(z["meta_tight"][0])
     t, fwd = hip_forward(sc, gpu_device)
     check_forward(sc, fr, fwd, gpu_device)
     assert not fr.fragile.any()  # the fixtures were chosen without fragile pixels: full-strength gradients
@@ -148,7 +159,10 @@ def test_reference_known_answer_through_hip(gpu_device):
     t, fwd = hip_forward(sc, gpu_device)
     v = G.state_views(fwd[5], fwd[6], fwd[7], 1, fwd[0], 640, 480)
     sp = v["splats"].cpu().numpy()[0]
-    assert fwd[0] == e["tiles"] and int(fwd[4][0]) == e["radius"]
+    assert int(fwd[4][0]) == e["radius"]
+    # the reference emits the whole 5 x 5 tile square of the 33 px radius (25 instances); the product emits the
+    # tiles its alpha >= 1/255 footprint box overlaps (the splat is ~6 x 2.5 px sigma: far fewer)
+    assert fwd[0] == O.forward(sc, tight=True).R <= e["tiles"] == O.forward(sc).R
     assert np.allclose(sp[0:2], e["xy"], atol=1e-4, rtol=0) and np.allclose(sp[2:5], e["conic"], atol=1e-6, rtol=0)
 
 
@@ -165,7 +179,7 @@ def test_empty_input_is_a_noop(gpu_device):
 def test_everything_culled(gpu_device):
     sc = S.make_scene(500, 100, 60, 8)
     sc["means3D"][:, 2] = -2.0
-    fr = O.forward(sc)
+    fr = O.forward(sc, tight=True)
     t, fwd = hip_forward(sc, gpu_device)
     assert fwd[0] == 0 == fr.R
     assert torch.equal(fwd[1], torch.ones_like(fwd[1])) and not fwd[3].any()  # background only
@@ -178,7 +192,7 @@ def _variant(P=1500, W=200, H=120, seed=13, D=1):
 
 
 def _full_check(sc, dev, seed=13):
-    fr = O.forward(sc)
+    fr = O.forward(sc, tight=True)
     t, fwd = hip_forward(sc, dev)
     check_forward(sc, fr, fwd, dev)
     dcol, dacc = masked_grads(sc["W"], sc["H"], seed, fr.fragile)
@@ -245,7 +259,7 @@ def test_large_image_many_tile_bits(gpu_device):
     partial tiles on both borders."""
     sc = S.make_scene(30_000, 3000, 1700, 18, sh_degree=0)
     O.set_threads(min(O.max_threads(), 16))
-    fr = O.forward(sc, keep_handle=False)
+    fr = O.forward(sc, keep_handle=False, tight=True)
     t, fwd = hip_forward(sc, gpu_device, debug=False)
     check_forward(sc, fr, fwd, gpu_device)
     assert int(fr.ranges.max()) == fr.R and fr.ranges.shape[0] == 188 * 107
@@ -399,7 +413,7 @@ def test_c3_per_gaussian_stage_matches_oracle_on_a_subsample(c3, gpu_device):
     sub = dict(sc)
     for k in ("means3D", "scales", "rotations", "opacities", "shs"):
         sub[k] = sc[k][idx]
-    fr = O.forward(sub, keep_handle=False)
+    fr = O.forward(sub, keep_handle=False, tight=True)
     v = G.state_views(fwd[5], fwd[6], fwd[7], 2_000_000, fwd[0], 1920, 1080)
     ti = torch.from_numpy(idx).to(gpu_device)
     assert np.array_equal(fwd[4][ti].cpu().numpy(), fr.radii)
@@ -441,6 +455,6 @@ def test_c2_full_parity_with_oracle(gpu_device):
     P, W, H, seed = S.CONFIGS["C2"]
     sc = S.make_scene(P, W, H, seed)
     O.set_threads(min(O.max_threads(), 16))  # the GPU box's CPU share
-    fr = O.forward(sc, keep_handle=False)
+    fr = O.forward(sc, keep_handle=False, tight=True)
     t, fwd = hip_forward(sc, gpu_device, debug=False)
     check_forward(sc, fr, fwd, gpu_device)

@@ -58,6 +58,41 @@ def test_oracle_reproduces_golden(name):
     for k, v in g.items():
         ref = z["bw_" + k]
         assert np.allclose(v, ref, atol=1e-6 * float(np.abs(ref).max()), rtol=1e-5), k
+    ft = O.forward(sc, tight=True)  # the product's culled tile rectangles: integer stages pinned as well
+    assert ft.R == int(z["meta_tight"][0])
+    for k in ("tiles_touched", "point_offsets", "keys", "point_list", "ranges", "n_contrib"):
+        assert np.array_equal(getattr(ft, k), z["tw_" + k]), k
+
+
+@pytest.mark.parametrize("P,W,H,seed,D", [(300, 70, 50, 11, 3), (2500, 257, 131, 4, 2), (10_000, 640, 480, 1, 0),
+                                          (6000, 320, 200, 16, 0), (400, 5, 3, 19, 1)])
+def test_tile_culling_leaves_images_and_gradients_bit_identical(P, W, H, seed, D):
+    """The product emits a (Gaussian, tile) instance only where the Gaussian's alpha >= 1/255 footprint box
+    overlaps the tile (oracle tight mode restates that rule).  The reference emits the whole 3-sigma square and
+    skips such instances pixel by pixel, so nothing observable may change: every image, the radii and every
+    gradient must be BIT-identical between the two modes; only the list lengths shrink."""
+    sc = S.make_scene(P, W, H, seed, sh_degree=D)
+    if P == 6000:  # a few screen-filling splats + low-opacity ones
+        sc["means3D"][:20, 2] = 1.0
+        sc["scales"][:20] = 0.29
+        sc["opacities"][100:300] = 0.003
+        sc["opacities"][300:500] = 0.0045
+    O.set_threads(1)
+    a, b = O.forward(sc), O.forward(sc, tight=True)
+    for k in ("radii", "means2D", "depths", "conic_opacity", "out_color", "out_depth", "out_acc", "final_T",
+              "fragile"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    assert (b.tiles_touched <= a.tiles_touched).all() and b.R <= a.R
+    if P >= 2500:
+        assert b.R < 0.9 * a.R
+    dcol, dacc = S.make_upstream_grads(W, H, seed)
+    ga, gb = O.backward(a, sc, dcol, dacc), O.backward(b, sc, dcol, dacc)
+    for k in ga:
+        assert np.array_equal(ga[k], gb[k]), k
+    # every instance of the culled list is an instance of the reference list, in the same relative order
+    ia = set(zip((a.keys >> np.uint64(32)).tolist(), a.point_list.tolist()))
+    ib = list(zip((b.keys >> np.uint64(32)).tolist(), b.point_list.tolist()))
+    assert all(x in ia for x in ib)
 
 
 def test_small_matrix_helpers_match_the_references_glm():
