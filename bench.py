@@ -47,14 +47,12 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
     R = instances, R_bwd = sum over tiles of tile_last (list entries the backward has to walk)."""
     kb = 2 if tiles <= 65536 else 4
     return {
-        "k_preprocess": P * (44 + 12 * M) + P * 8 + P_vis * 77,   # in: 56 B @M=1; out: radii+tiles, 48-B splat, cov3D, depth, clamp
-        "k_scan_block_sums": (P // 256 + 1) * 8,
-        "k_depth_keys": P * 20,
+        # in: 56 B @M=1; out: radii+tiles+gpack, 48-B splat, cov3D, depth, clamp, depth-sort pair, scratch clear
+        "k_preprocess": P * (44 + 12 * M) + P * 25 + P_vis * 77,
+        "k_point_offsets": P * 8,                                 # debug forwards only
         "k_sort_hist[depth]": P * 4, "k_sort_scatter[depth]": P * 16,
-        "k_sort_scan_chunks[depth]": (P // 4096 + 1) * 2048, "k_sort_scan_top[depth]": 0,
-        "k_sorted_block_sums": P * 8,
-        "k_sorted_offsets": P * 8 + P_vis * 20 + P * 12 + P_vis * 8,
-        "k_emit_chunks": P * 8,
+        # order + gpack gather in; soff, sn, srect, sinv out; slotinfo for the Gaussians with instances
+        "k_scan_offsets": P * 12 + P * 16 + P_vis * 8,
         # tile ids are 16-bit when the image has <= 65536 tiles (kb bytes per key), Gaussian ids 32-bit
         "k_emit": R * (kb + 4) + P_vis * 16,
         "k_sort_hist": R * kb, "k_sort_scatter": R * 2 * (kb + 4),  # (tile, id): read + write per pass

@@ -59,7 +59,7 @@ void prof_end(hipStream_t s) {
 }
 }  // namespace gsr
 static const char* const kKernelNames[K_COUNT] = {
-    "k_preprocess", "k_scan_block_sums", "k_depth_keys", "k_sorted_block_sums", "k_sorted_offsets", "k_emit_chunks", "k_emit",
+    "k_preprocess", "k_point_offsets", "k_scan_offsets", "k_emit",
     "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top", "k_sort_scatter", "k_tile_ranges", "k_blend_forward",
     "k_blend_backward", "k_compact_touched", "k_gather_records", "k_gaussian_backward", "k_mark_visible", "k_sort_hist[depth]",
     "k_sort_scan_chunks[depth]", "k_sort_scan_top[depth]", "k_sort_scatter[depth]", "k_activate",
@@ -174,6 +174,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   if (!colors_precomp && (D < 0 || D > 3 || M < (D + 1) * (D + 1) || M > 16))
     return fail(GSR_ERR_UNSUPPORTED, "SH degree %d with %d coefficients is not supported (D<=3, (D+1)^2<=M<=16)", D, M);
   if (width > 1023 * TILE || height > 1023 * TILE) return fail(GSR_ERR_UNSUPPORTED, "image larger than 16368 px");
+  if (P >= (1 << 30)) return fail(GSR_ERR_UNSUPPORTED, "2^30 or more Gaussians");
   if (!(tan_fovx > 0.f) || !(tan_fovy > 0.f)) return fail(GSR_ERR_INVALID_ARGUMENT, "tan_fov must be > 0");
 
   const FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
@@ -184,36 +185,37 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   GeomState g = GeomState::carve(gblob, (size_t)P);
   ImageState im = ImageState::carve(iblob, width, height);
 
-  const int nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
-  STAGE(launch_preprocess(fp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
-                          projmatrix, cam_pos, g, radii, stream));
   // R must be known on the host to size the binning blob, where the reference has its blocking
-  // cudaMemcpy (rasterizer_impl.cu:277).  Here the scan kernel stores (ticket, R) into a page-locked,
-  // host-mapped word and the host polls that word: no copy engine, no completion interrupt (whose
-  // wake-up latency was measured at up to 30 ms on virtualised hosts), and the host gets R as soon as
-  // the scan retires -- the per-Gaussian depth sort, which does not depend on R, is already enqueued
+  // cudaMemcpy (rasterizer_impl.cu:277).  Here the last workgroup of k_preprocess stores (ticket, R) into a
+  // page-locked, host-mapped word and the host polls that word: no copy engine, no completion interrupt
+  // (whose wake-up latency was measured at up to 30 ms on virtualised hosts), and the host gets R as soon as
+  // the first kernel retires -- the per-Gaussian depth sort, which does not depend on R, is already enqueued
   // behind it and runs while the host sizes and allocates the binning blob.
+  // A host thread is inside this wait for one forward at a time, so the mailbox and the kernel's
+  // "workgroups done" counter (which its last workgroup resets) can be per-thread singletons.
   static thread_local unsigned long long* mailbox = nullptr;  // host pointer
   static thread_local unsigned long long* mailbox_dev = nullptr;
+  static thread_local unsigned long long* done_counter = nullptr;  // device: (workgroups done << 40 | sum)
   static thread_local uint32_t ticket = 0;
   if (!mailbox) {
     void* h = nullptr;
     void* d = nullptr;
+    void* c = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer(&d, h, 0) != hipSuccess)
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipMalloc(&c, 64) != hipSuccess ||
+        hipMemset(c, 0, 64) != hipSuccess)
       return fail(GSR_ERR_HIP, "cannot allocate the host-mapped mailbox: %s", hipGetErrorString(hipGetLastError()));
     mailbox = static_cast<unsigned long long*>(h);
     mailbox_dev = static_cast<unsigned long long*>(d);
+    done_counter = static_cast<unsigned long long*>(c);
     *mailbox = 0;
+    (void)hipDeviceSynchronize();  // the counter is zero before any stream uses it
   }
   ticket = ticket == 0xFFFFFFFFu ? 1u : ticket + 1u;  // never 0: the mailbox starts at ticket 0
-  STAGE(launch_scan_block_sums(g.block_sums, nb, g.total, mailbox_dev, ticket, stream));
-  STAGE(launch_depth_keys(fp, g, g.dkeysA, g.order, stream));
-  STAGE(launch_sort_pairs(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, 32, /*start_in_A=*/true,
-                          /*is_depth_sort=*/true, /*key16=*/false, stream));
-  STAGE(launch_sorted_block_sums(fp, g, stream));
-  STAGE(launch_scan_block_sums(g.block_sums2, nb, g.total + 1, nullptr, 0, stream));
-  STAGE(launch_sorted_offsets(fp, g, im.ranges, stream));
+  STAGE(launch_preprocess(fp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
+                          projmatrix, cam_pos, g, radii, done_counter, mailbox_dev, ticket, stream));
+  STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, stream));
+  if (debug) STAGE(launch_point_offsets(fp, g, stream));  // the reference's array, for the views only
   uint32_t R_host = 0;
   const std::chrono::steady_clock::time_point t_enqueued = std::chrono::steady_clock::now();
   {
@@ -229,7 +231,10 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       const hipError_t q = hipStreamQuery(stream);
       if (q == hipSuccess) {  // everything enqueued has retired, so the word has been stored
         const unsigned long long v2 = __atomic_load_n(mailbox, __ATOMIC_ACQUIRE);
-        if ((uint32_t)(v2 >> 32) != ticket) return fail(GSR_ERR_HIP, "instance count was not published");
+        if ((uint32_t)(v2 >> 32) != ticket) {
+          (void)hipMemset(done_counter, 0, 64);  // do not leave a half-counted launch behind
+          return fail(GSR_ERR_HIP, "instance count was not published");
+        }
         R_host = (uint32_t)v2;
         break;
       }
@@ -256,6 +261,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
   const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
   const bool key16 = tiles <= 65536;  // tile ids fit 16 bits for every image up to 4096 x 4096
+  STAGE(launch_scan_offsets(fp, g, R, b.chunk_first, im.ranges, stream));
   STAGE(launch_emit(fp, g, R, b.chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB,
                     b.inst_flag, key16, stream));
   STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, R, tile_bits, start_in_A,

@@ -54,15 +54,42 @@ struct SortScratch {  // scratch of one radix sort over n (u32 key, u32 value) p
   }
 };
 
+// Scratch of the single-launch (decoupled look-back) kernels -- the depth sort (radix_sort.hip: all-digit
+// histograms, tile tickets, per-(pass, tile, digit) status words) and the slot-offset scan (k_scan_offsets:
+// ticket + one 64-bit status word per 4096 Gaussians) -- in ONE array that k_preprocess clears as a side job.
+constexpr int PRE_SUB = 4;      // 256-Gaussian blocks walked by one k_preprocess workgroup
+constexpr int SCAN_ITEMS = 16;                    // consecutive Gaussians per thread in k_scan_offsets
+constexpr int SCAN_TILE = PRE_BLOCK * SCAN_ITEMS;  // 4096
+struct DepthSortScratch {
+  uint32_t* words;
+  size_t nwords;
+  size_t scan_off;  // word offset of the scan's status array
+  __host__ __device__ uint32_t* ghist() const { return words; }           // [4][256]
+  __host__ __device__ uint32_t* tickets() const { return words + 1024; }  // [0..3] sort passes, [4] scan (+ padding)
+  __host__ __device__ uint32_t* status(int pass, int ntiles) const {      // [4][ntiles][256]
+    return words + 1088 + (size_t)pass * ntiles * 256;
+  }
+  __host__ __device__ unsigned long long* scan_status() const {           // [ceil(n / SCAN_TILE)]
+    return reinterpret_cast<unsigned long long*>(words + scan_off);
+  }
+  static void carve(Carver& c, size_t n, DepthSortScratch& s) {
+    const size_t ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const size_t nscan = (n + SCAN_TILE - 1) / SCAN_TILE;
+    s.scan_off = 1088 + 4 * ntiles * 256;  // even: the 64-bit status words are 8-byte aligned
+    s.nwords = s.scan_off + 2 * nscan;
+    s.words = c.take<uint32_t>(s.nwords);
+  }
+};
+
 struct GeomState {
   float* depths;
   int32_t* radii;
   float4* splats;
   float* cov3D;
   uint32_t* tiles_touched;
-  uint32_t* point_offsets;  // inclusive scan of tiles_touched in Gaussian-id order (= the reference's array)
+  uint32_t* point_offsets;  // inclusive scan of tiles_touched in Gaussian-id order (= the reference's array);
+                            // not used by this pipeline: filled only by a debug forward (for the views)
   uint8_t* clamped;         // bit0..2
-  uint32_t* block_sums;     // per 256-Gaussian block (id order): sum of tiles_touched -> exclusive offsets
   uint32_t* total;          // [1] num_rendered, device side
   uint2* slotinfo;          // {first slot of the Gaussian's instance run, x0 | y0 << 10 | rect_width << 20}
   uint2* gpack;             // {tiles_touched, packed rect} per Gaussian: ONE 8-byte gather in depth order
@@ -70,18 +97,16 @@ struct GeomState {
   uint32_t* dkeysA;         // [P] depth-sort ping-pong buffers
   uint32_t* dkeysB;
   uint32_t* dvalsB;
-  uint32_t* block_sums2;    // per 256-block of `order`: sum of tiles_touched -> exclusive offsets
   uint32_t* soff;           // [P+1] first instance slot of order[i] (exclusive scan in depth order); soff[P] = R
   uint32_t* sn;             // [P] tiles_touched of order[i]
   uint32_t* srect;          // [P] packed tile rect of order[i]: x0 | y0 << 10 | width << 20
   uint32_t* sinv;           // [P] ceil(2^32 / width) of order[i] (exact division by multiply-high)
   uint8_t* touched;         // [P] 1 = the blend backward wrote at least one gradient record for this Gaussian
   uint32_t* tlist;          // [P] compacted ids of touched Gaussians (backward); count in total[2]
-  SortScratch dsort;
+  DepthSortScratch dsort;
   static GeomState carve(char* blob, size_t P, size_t* bytes = nullptr) {
     Carver c(blob);
     GeomState g;
-    size_t nb = (P + PRE_BLOCK - 1) / PRE_BLOCK;
     g.depths = c.take<float>(P);
     g.radii = c.take<int32_t>(P);
     g.splats = c.take<float4>(P * SPLAT_F4);
@@ -89,7 +114,6 @@ struct GeomState {
     g.tiles_touched = c.take<uint32_t>(P);
     g.point_offsets = c.take<uint32_t>(P);
     g.clamped = c.take<uint8_t>(P);
-    g.block_sums = c.take<uint32_t>(nb + 1);
     g.total = c.take<uint32_t>(64);
     g.slotinfo = c.take<uint2>(P);
     g.gpack = c.take<uint2>(P);
@@ -97,14 +121,13 @@ struct GeomState {
     g.dkeysA = c.take<uint32_t>(P);
     g.dkeysB = c.take<uint32_t>(P);
     g.dvalsB = c.take<uint32_t>(P);
-    g.block_sums2 = c.take<uint32_t>(nb + 1);
     g.soff = c.take<uint32_t>(P + 1);
     g.sn = c.take<uint32_t>(P);
     g.srect = c.take<uint32_t>(P);
     g.sinv = c.take<uint32_t>(P);
     g.touched = c.take<uint8_t>(P);
     g.tlist = c.take<uint32_t>(P);
-    SortScratch::carve(c, P, g.dsort);
+    DepthSortScratch::carve(c, P, g.dsort);
     if (bytes) *bytes = align_up(c.off) + ALIGN;
     return g;
   }
@@ -177,12 +200,11 @@ struct FrameParams {
 hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const float* scales, const float* rotations,
                              const float* opacities, const float* shs, const float* cov3D_precomp,
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,
-                             GeomState g, int* radii_out, hipStream_t s);
-hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, unsigned long long* publish,
-                                  uint32_t ticket, hipStream_t s);
-hipError_t launch_depth_keys(const FrameParams& fp, GeomState g, uint32_t* keys_out, uint32_t* vals_out, hipStream_t s);
-hipError_t launch_sorted_block_sums(const FrameParams& fp, GeomState g, hipStream_t s);
-hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, uint2* ranges, hipStream_t s);
+                             GeomState g, int* radii_out, unsigned long long* done_word,
+                             unsigned long long* publish, uint32_t ticket, hipStream_t s);
+hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
+hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint2* ranges,
+                               hipStream_t s);
 hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
                        uint32_t* ivals_out, uint8_t* inst_flag, bool key16, hipStream_t s);
 hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningState b, float* dL_dmean2D,
@@ -191,6 +213,8 @@ hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningStat
 // (keysA, valsA) and (keysB, valsB), starting in A when start_in_A.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
                              int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16, hipStream_t s);
+hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
+                             int n, hipStream_t s);
 hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, bool key16, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, hipStream_t s);
@@ -226,7 +250,7 @@ inline int sort_digit_bits(int end_bit) { const int p = sort_passes(end_bit); re
 
 // Kernel ids for the optional event profiler (api.hip); order = gsr_kernel_name().
 enum KernelId {
-  K_PREPROCESS = 0, K_SCAN_BLOCKS, K_DEPTH_KEYS, K_SORTED_SUMS, K_SORTED_OFFSETS, K_EMIT_CHUNKS, K_EMIT, K_SORT_HIST,
+  K_PREPROCESS = 0, K_POINT_OFFSETS, K_SCAN_OFFSETS, K_EMIT, K_SORT_HIST,
   K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_COMPACT_TOUCHED,
   K_GATHER_RECORDS, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_DSORT_HIST, K_DSORT_SCAN_CHUNKS, K_DSORT_SCAN_TOP,
   K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_LOSS_FWD, K_LOSS_FINALIZE, K_LOSS_BWD, K_COUNT

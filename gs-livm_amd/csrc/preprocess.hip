@@ -134,9 +134,15 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos, GeomState g,
-    int* __restrict__ radii_out) {
-  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  uint32_t tiles = 0, rect_packed = 0;
+    int* __restrict__ radii_out, unsigned long long* __restrict__ done_word,
+    unsigned long long* __restrict__ publish,
+    const uint32_t ticket) {
+  // A workgroup walks PRE_SUB consecutive blocks of 256 Gaussians: 4x fewer workgroups means 4x fewer
+  // same-address atomics for the instance count below (they retire one at a time, ~5 ns each).
+  uint32_t tiles_wg = 0;
+  for (int sub = 0; sub < PRE_SUB; sub++) {
+  const int idx = (blockIdx.x * PRE_SUB + sub) * PRE_BLOCK + threadIdx.x;
+  uint32_t tiles = 0, rect_packed = 0, dkey = 0xFFFFFFFFu;
   int radius = 0;
   if (idx < fp.P) {
     const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
@@ -250,6 +256,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
           radius = (int)my_radius;
           tiles = (x1 > x0 && y1 > y0) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
           rect_packed = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
+          if (tiles) dkey = __float_as_uint(pvz);  // depth > 0.2: the bit pattern orders like the value
           g.depths[idx] = pvz;
           float4* rec = g.splats + (size_t)idx * SPLAT_F4;
           rec[0] = make_float4(pixx, pixy, conx, cony);
@@ -265,149 +272,198 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     g.gpack[idx] = make_uint2(tiles, tiles ? rect_packed : 0u);
     g.touched[idx] = 0;  // backward bookkeeping starts clean (the backward clears what it sets)
     if (idx == 0) g.total[2] = 0u;
+    // (key, value) pairs of the per-Gaussian depth sort; Gaussians without instances sort to the end
+    g.dkeysA[idx] = dkey;
+    g.order[idx] = (uint32_t)idx;
   }
-  // per-block sum of tiles_touched -> block_sums[blockIdx.x]
+  tiles_wg += tiles;
+  }
+  // side job: clear the depth sort's histograms, tickets and look-back status words
+  for (size_t w = (size_t)blockIdx.x * PRE_BLOCK + threadIdx.x; w < g.dsort.nwords; w += (size_t)gridDim.x * PRE_BLOCK)
+    g.dsort.words[w] = 0u;
   __shared__ uint32_t wsum[PRE_BLOCK / 64];
-  const uint32_t ws = wave_sum_u32(tiles);
+  const uint32_t ws = wave_sum_u32(tiles_wg);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
   __syncthreads();
-  if (threadIdx.x == 0) g.block_sums[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+  // num_rendered without a scan launch and without a release fence (an agent-scope fence writes back the XCD's
+  // L2: ~75 ns per workgroup when 7813 of them do it): every workgroup adds (1 << 40 | its sum) to ONE 64-bit
+  // word, so the count of finished workgroups and the running total travel in the same atomic.  The workgroup
+  // that sees count == grid - 1 in the returned value is last: it knows the total, publishes it to the host
+  // mailbox (a page-locked, host-mapped word the host polls: no copy engine, no interrupt) and resets the word,
+  // which is library-owned device memory, for the next call.
+  if (threadIdx.x == 0) {
+    const uint32_t mine = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    const unsigned long long old = atomicAdd(done_word, (1ull << 40) | (unsigned long long)mine);
+    if ((old >> 40) == (unsigned long long)gridDim.x - 1ull) {
+      const unsigned long long tot = (old & ((1ull << 40) - 1ull)) + mine;
+      const uint32_t r = tot > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)tot;  // the host rejects R >= 2^31
+      g.total[0] = r;
+      __hip_atomic_store(done_word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (publish)
+        __hip_atomic_store(publish, ((unsigned long long)ticket << 32) | r, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_SYSTEM);  // self-contained value: no release (= L2 write-back) needed
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
-// F2.  One workgroup: exclusive scan of block_sums[nb] in place, total -> g.total[0].
-// Together with the in-block scan in k_duplicate this is cub::DeviceScan::InclusiveSum
-// (reference rasterizer_impl.cu:270-273).
+// Debug only (the views of a debug forward): point_offsets = inclusive scan of tiles_touched in
+// Gaussian-id order, the reference's array (rasterizer_impl.cu:270-273).  The pipeline itself never
+// reads it (slots are assigned in depth order by k_scan_offsets), so this is one workgroup walking
+// the array: simple, and off the production path.
 // ------------------------------------------------------------------------------------------------
-// `publish` (optional) is a host-mapped, page-locked 8-byte word: the total and the caller's ticket go out
-// in one store, so the host can pick the value up by polling memory instead of waiting for a copy engine
-// and a completion interrupt.
-__global__ __launch_bounds__(1024) void k_scan_block_sums(uint32_t* __restrict__ sums, int nb,
-                                                          uint32_t* __restrict__ total,
-                                                          unsigned long long* __restrict__ publish,
-                                                          uint32_t ticket) {
+__global__ __launch_bounds__(1024) void k_point_offsets(const int P, const uint32_t* __restrict__ tiles_touched,
+                                                        uint32_t* __restrict__ point_offsets) {
   __shared__ uint32_t wtot[16];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) carry_s = 0;
   __syncthreads();
-  for (int base = 0; base < nb; base += 1024) {
+  for (int base = 0; base < P; base += 1024) {
     const int i = base + tid;
-    const uint32_t v = i < nb ? sums[i] : 0u;
+    const uint32_t v = i < P ? tiles_touched[i] : 0u;
     const uint32_t inc = wave_incl_scan_u32(v, lane);
     if (lane == 63) wtot[w] = inc;
     __syncthreads();
     uint32_t woff = 0;
     for (int k = 0; k < w; k++) woff += wtot[k];
     const uint32_t carry = carry_s;
-    if (i < nb) sums[i] = carry + woff + inc - v;
+    if (i < P) point_offsets[i] = carry + woff + inc;
     __syncthreads();
     if (tid == 1023) carry_s = carry + woff + inc;
     __syncthreads();
   }
-  if (tid == 0) {
-    total[0] = carry_s;
-    if (publish) {
-      __hip_atomic_store(publish, ((unsigned long long)ticket << 32) | carry_s, __ATOMIC_RELEASE,
-                         __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------
-// F3'.  point_offsets = inclusive scan of tiles_touched in Gaussian-id order (the reference's
-// array, rasterizer_impl.cu:270-273; block_sums already holds the exclusive block offsets), and the
-// (key, value) pairs of the per-Gaussian depth sort: key = bits(depth) for visible Gaussians
-// (depth > 0.2, so the bit pattern orders like the value), 0xFFFFFFFF for culled ones.
-// ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PRE_BLOCK) void k_depth_keys(const FrameParams fp, GeomState g,
-                                                          uint32_t* __restrict__ keys_out,
-                                                          uint32_t* __restrict__ vals_out) {
-  __shared__ uint32_t wtot[PRE_BLOCK / 64];
-  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t n = idx < fp.P ? g.tiles_touched[idx] : 0u;
-  const uint32_t inc = wave_incl_scan_u32(n, lane);
-  if (lane == 63) wtot[w] = inc;
-  __syncthreads();
-  uint32_t off = g.block_sums[blockIdx.x];
-  for (int k = 0; k < w; k++) off += wtot[k];
-  if (idx < fp.P) {
-    g.point_offsets[idx] = off + inc;
-    keys_out[idx] = n ? __float_as_uint(g.depths[idx]) : 0xFFFFFFFFu;
-    vals_out[idx] = (uint32_t)idx;
-  }
-}
-
-// Per 256-block of the depth-sorted order: ONE 8-byte gather per Gaussian brings (tiles_touched, rect) into
-// depth order (sn, srect, sinv are then read coalesced by k_sorted_offsets / k_emit); block sums of
-// tiles_touched -> block_sums2 (scanned by k_scan_block_sums).
-__global__ __launch_bounds__(PRE_BLOCK) void k_sorted_block_sums(const FrameParams fp, GeomState g) {
-  __shared__ uint32_t wsum[PRE_BLOCK / 64];
-  const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  uint32_t n = 0;
-  if (i < fp.P) {
-    const uint2 gp = g.gpack[g.order[i]];
-    n = gp.x;
-    const uint32_t rw = gp.y >> 20;
-    g.sn[i] = n;
-    g.srect[i] = gp.y;
-    g.sinv[i] = n ? 0xFFFFFFFFu / rw + 1u : 0u;  // ceil(2^32 / rw) for rw > 1 (wraps to 0 for rw == 1: k_emit)
-  }
-  const uint32_t ws = wave_sum_u32(n);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
-  __syncthreads();
-  if (threadIdx.x == 0) g.block_sums2[blockIdx.x] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-// ------------------------------------------------------------------------------------------------
-// F4.  Replaces duplicateWithKeys (reference rasterizer_impl.cu:64-101).  Gaussians are visited in
-// depth order; Gaussian order[i] gets the contiguous slot run [soff[i], soff[i+1]) and its instances
-// are emitted in the reference's row-major tile order with key = tile id, value = Gaussian id.  The
-// depth part of the reference's 64-bit key is implied by the emission order, which the stable tile
-// sort preserves.  A slot is also the index of the instance's gradient record in the backward.
+// F4.  Replaces duplicateWithKeys (reference rasterizer_impl.cu:64-101) and the InclusiveSum before it.
+// Gaussians are visited in depth order; Gaussian order[i] gets the contiguous slot run
+// [soff[i], soff[i+1]) and its instances are emitted in the reference's row-major tile order with
+// key = tile id, value = Gaussian id.  The depth part of the reference's 64-bit key is implied by the
+// emission order, which the stable tile sort preserves.  A slot is also the index of the instance's
+// gradient record in the backward.
 //
-// k_sorted_offsets: exclusive scan in depth order -> soff, packed rect + reciprocal per Gaussian.
-// k_emit is OUTPUT-centric: every workgroup owns EMIT_CHUNK consecutive slots, finds the Gaussians
-// covering them with a 64-ary wave search over soff, stages their descriptors in LDS and each thread
-// turns its slots into (tile, id) by bisection + an exact multiply-high division.  Work per
-// workgroup is constant however skewed the tile counts are (the nearest Gaussians own >1000 tiles
-// each and sit next to each other in depth order), and all stores are coalesced.
+// k_scan_offsets: ONE launch for the exclusive scan in depth order (decoupled look-back over workgroups of
+// 4096 Gaussians: ticketed tiles, one 64-bit status word each, wave-wide look-back window) that also
+//   * gathers (tiles_touched, rect) into depth order with one 8-byte load per Gaussian (sn, srect, sinv are
+//     then read coalesced by k_emit), writes slotinfo for the backward,
+//   * writes, for every EMIT_CHUNK boundary inside a Gaussian's run, the depth-order index of that
+//     Gaussian (chunk_first: saves k_emit two dependent searches per workgroup),
+//   * zeroes the tile ranges (the reference's cudaMemset, rasterizer_impl.cu:311).
+// k_emit is OUTPUT-centric: every workgroup owns EMIT_CHUNK consecutive slots, stages the descriptors
+// of the Gaussians covering them in LDS and each thread turns its slots into (tile, id) by bisection +
+// an exact multiply-high division.  Work per workgroup is constant however skewed the tile counts are
+// (the nearest Gaussians own >1000 tiles each and sit next to each other in depth order), and all
+// stores are coalesced.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PRE_BLOCK) void k_sorted_offsets(const FrameParams fp, GeomState g,
-                                                              uint2* __restrict__ ranges) {
+constexpr unsigned long long SC_GLOBAL = 2ull << 32, SC_LOCAL = 1ull << 32;
+
+__global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp, GeomState g, const int R,
+                                                            uint32_t* __restrict__ chunk_first,
+                                                            uint2* __restrict__ ranges) {
   __shared__ uint32_t wtot[PRE_BLOCK / 64];
-  const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  // side job: (0, 0) for the tiles no instance lands in (the reference's cudaMemset, rasterizer_impl.cu:311)
-  for (int t = i; t < fp.gx * fp.gy; t += gridDim.x * PRE_BLOCK) ranges[t] = make_uint2(0u, 0u);
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t n = i < fp.P ? g.sn[i] : 0u;
-  const uint32_t inc = wave_incl_scan_u32(n, lane);
+  __shared__ uint32_t s_tile, s_prefix;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // side job: (0, 0) for the tiles no instance lands in
+  for (int t = blockIdx.x * PRE_BLOCK + tid; t < fp.gx * fp.gy; t += gridDim.x * PRE_BLOCK)
+    ranges[t] = make_uint2(0u, 0u);
+  if (tid == 0) s_tile = atomicAdd(g.dsort.tickets() + 4, 1u);  // every lower tile is already running
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const int i0 = (int)(tile * SCAN_TILE) + tid * SCAN_ITEMS;
+  uint32_t id[SCAN_ITEMS], n[SCAN_ITEMS], rect[SCAN_ITEMS];
+  if (i0 + SCAN_ITEMS <= fp.P) {
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS / 4; q++) {
+      const uint4 o = *reinterpret_cast<const uint4*>(g.order + i0 + 4 * q);
+      id[4 * q] = o.x; id[4 * q + 1] = o.y; id[4 * q + 2] = o.z; id[4 * q + 3] = o.w;
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) id[k] = i0 + k < fp.P ? g.order[i0 + k] : 0xFFFFFFFFu;
+  }
+  uint32_t sum = 0;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    const uint2 gp = id[k] != 0xFFFFFFFFu ? g.gpack[id[k]] : make_uint2(0u, 0u);
+    n[k] = gp.x;
+    rect[k] = gp.y;
+    sum += gp.x;
+  }
+  const uint32_t inc = wave_incl_scan_u32(sum, lane);
   if (lane == 63) wtot[w] = inc;
   __syncthreads();
-  uint32_t off = g.block_sums2[blockIdx.x];
+  const uint32_t agg = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+  if (w == 0) {
+    unsigned long long* st = g.dsort.scan_status();
+    uint32_t prefix = 0;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(st, SC_GLOBAL | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(st + tile, SC_LOCAL | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int base = (int)tile - 1;  // lane L inspects tile base - L; beyond tile 0 counts as a known prefix of 0
+      for (;;) {
+        const int t = base - lane;
+        const unsigned long long v =
+            t >= 0 ? __hip_atomic_load(st + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SC_GLOBAL;
+        const uint32_t flag = (uint32_t)(v >> 32);
+        const uint64_t mg = __ballot(flag == 2u), mn = __ballot(flag == 0u);
+        const int fg = mg ? __builtin_ctzll(mg) : 64;  // nearest tile whose inclusive prefix is known
+        const uint64_t nearer = fg == 64 ? ~0ull : ((1ull << fg) - 1ull);
+        if (mn & nearer) {  // a nearer tile has not published yet
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        prefix += wave_sum_u32(lane <= fg ? (uint32_t)v : 0u);
+        if (fg < 64) break;
+        base -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(st + tile, SC_GLOBAL | (unsigned long long)(prefix + agg), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_prefix = prefix;
+  }
+  __syncthreads();
+  uint32_t off = s_prefix + inc - sum;  // exclusive offset of this thread's first Gaussian
   for (int k = 0; k < w; k++) off += wtot[k];
-  off += inc - n;  // exclusive
-  if (i >= fp.P) return;
-  g.soff[i] = off;
-  if (n) g.slotinfo[g.order[i]] = make_uint2(off, g.srect[i]);
-  if (i == fp.P - 1) g.soff[fp.P] = off + n;
-}
-
-// For every chunk boundary k*EMIT_CHUNK, the depth-order index of the Gaussian whose run covers that slot
-// (each Gaussian writes the boundaries inside its own run: usually none or one, dozens for the nearest
-// Gaussians).  chunk_first[nchunks] = the last Gaussian that owns any slot.  Saves k_emit two dependent
-// multi-step searches per workgroup.
-__global__ __launch_bounds__(PRE_BLOCK) void k_emit_chunks(const FrameParams fp, GeomState g, const int R,
-                                                           uint32_t* __restrict__ chunk_first) {
-  const int i = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  if (i >= fp.P) return;
-  const uint32_t n = g.sn[i];
-  if (!n) return;
-  const uint32_t off = g.soff[i], end = off + n;
-  for (uint32_t k = (off + EMIT_CHUNK - 1) / EMIT_CHUNK; (unsigned long long)k * EMIT_CHUNK < end; k++)
-    chunk_first[k] = (uint32_t)i;
-  if (end == (uint32_t)R) chunk_first[(R + EMIT_CHUNK - 1) / EMIT_CHUNK] = (uint32_t)i;
+  if (i0 >= fp.P) return;
+  uint32_t offs[SCAN_ITEMS], inv[SCAN_ITEMS];
+  const uint32_t last_chunk = (uint32_t)((R + EMIT_CHUNK - 1) / EMIT_CHUNK);
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    offs[k] = off;
+    const uint32_t rw = rect[k] >> 20;
+    inv[k] = n[k] ? 0xFFFFFFFFu / rw + 1u : 0u;  // ceil(2^32 / rw) for rw > 1 (wraps to 0 for rw == 1: k_emit)
+    if (i0 + k < fp.P && n[k]) {
+      const uint32_t end = off + n[k];
+      g.slotinfo[id[k]] = make_uint2(off, rect[k]);
+      for (uint32_t c = (off + EMIT_CHUNK - 1) / EMIT_CHUNK; (unsigned long long)c * EMIT_CHUNK < end; c++)
+        chunk_first[c] = (uint32_t)(i0 + k);
+      if (end == (uint32_t)R) chunk_first[last_chunk] = (uint32_t)(i0 + k);
+    }
+    off += n[k];
+  }
+  if (i0 + SCAN_ITEMS <= fp.P) {
+#pragma unroll
+    for (int q = 0; q < SCAN_ITEMS / 4; q++) {
+      const int j = 4 * q;
+      *reinterpret_cast<uint4*>(g.soff + i0 + j) = make_uint4(offs[j], offs[j + 1], offs[j + 2], offs[j + 3]);
+      *reinterpret_cast<uint4*>(g.sn + i0 + j) = make_uint4(n[j], n[j + 1], n[j + 2], n[j + 3]);
+      *reinterpret_cast<uint4*>(g.srect + i0 + j) = make_uint4(rect[j], rect[j + 1], rect[j + 2], rect[j + 3]);
+      *reinterpret_cast<uint4*>(g.sinv + i0 + j) = make_uint4(inv[j], inv[j + 1], inv[j + 2], inv[j + 3]);
+    }
+  } else {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++)
+      if (i0 + k < fp.P) {
+        g.soff[i0 + k] = offs[k];
+        g.sn[i0 + k] = n[k];
+        g.srect[i0 + k] = rect[k];
+        g.sinv[i0 + k] = inv[k];
+      }
+  }
+  if (i0 + SCAN_ITEMS >= fp.P) g.soff[fp.P] = off;  // sentinel: = R
 }
 
 template <typename K>
@@ -846,51 +902,33 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float* 
 hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const float* scales, const float* rotations,
                              const float* opacities, const float* shs, const float* cov3D_precomp,
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,
-                             GeomState g, int* radii_out, hipStream_t s) {
+                             GeomState g, int* radii_out, unsigned long long* done_word,
+                             unsigned long long* publish, uint32_t ticket, hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps_k_preprocess(K_PREPROCESS, s);
-  hipLaunchKernelGGL(k_preprocess, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, means3D, scales, rotations, opacities, shs,
-                     cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out);
+  hipLaunchKernelGGL(k_preprocess, dim3((nb + PRE_SUB - 1) / PRE_SUB), dim3(PRE_BLOCK), 0, s, fp, means3D, scales, rotations, opacities, shs,
+                     cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket);
   return hipGetLastError();
 }
 
-hipError_t launch_scan_block_sums(uint32_t* sums, int nb, uint32_t* total, unsigned long long* publish,
-                                  uint32_t ticket, hipStream_t s) {
-  ProfScope ps(K_SCAN_BLOCKS, s);
-  hipLaunchKernelGGL(k_scan_block_sums, dim3(1), dim3(1024), 0, s, sums, nb, total, publish, ticket);
+// debug forwards only: the reference's point_offsets array for the views
+hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t s) {
+  ProfScope ps(K_POINT_OFFSETS, s);
+  hipLaunchKernelGGL(k_point_offsets, dim3(1), dim3(1024), 0, s, fp.P, g.tiles_touched, g.point_offsets);
   return hipGetLastError();
 }
 
-hipError_t launch_depth_keys(const FrameParams& fp, GeomState g, uint32_t* keys_out, uint32_t* vals_out,
-                             hipStream_t s) {
-  const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
-  ProfScope ps(K_DEPTH_KEYS, s);
-  hipLaunchKernelGGL(k_depth_keys, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, keys_out, vals_out);
-  return hipGetLastError();
-}
-
-hipError_t launch_sorted_block_sums(const FrameParams& fp, GeomState g, hipStream_t s) {
-  const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
-  ProfScope ps(K_SORTED_SUMS, s);
-  hipLaunchKernelGGL(k_sorted_block_sums, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g);
-  return hipGetLastError();
-}
-
-hipError_t launch_sorted_offsets(const FrameParams& fp, GeomState g, uint2* ranges, hipStream_t s) {
-  const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
-  ProfScope ps(K_SORTED_OFFSETS, s);
-  hipLaunchKernelGGL(k_sorted_offsets, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, ranges);
+hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint2* ranges,
+                               hipStream_t s) {
+  ProfScope ps(K_SCAN_OFFSETS, s);
+  hipLaunchKernelGGL(k_scan_offsets, dim3((fp.P + SCAN_TILE - 1) / SCAN_TILE), dim3(PRE_BLOCK), 0, s, fp, g, R,
+                     chunk_first, ranges);
   return hipGetLastError();
 }
 
 hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
                        uint32_t* ivals_out, uint8_t* inst_flag, bool key16, hipStream_t s) {
   if (R <= 0) return hipSuccess;
-  {
-    ProfScope ps(K_EMIT_CHUNKS, s);
-    hipLaunchKernelGGL(k_emit_chunks, dim3((fp.P + PRE_BLOCK - 1) / PRE_BLOCK), dim3(PRE_BLOCK), 0, s, fp, g, R,
-                       chunk_first);
-  }
   ProfScope ps(K_EMIT, s);
   const dim3 grid((R + EMIT_CHUNK - 1) / EMIT_CHUNK);
   if (key16)

@@ -122,20 +122,75 @@ __global__ __launch_bounds__(256) void k_sort_scan_top(uint32_t* __restrict__ ch
   if (lane == 0) digit_total[d] = carry;
 }
 
-template <typename K>
+// All four digit histograms of the 32-bit keys in one pass over them (single-launch-per-pass sort below):
+// LDS atomics per workgroup, then one global atomicAdd per non-empty bin.  ghist[4][256] is zero on entry.
+__global__ __launch_bounds__(256) void k_sort_hist_all(const uint32_t* __restrict__ keys, int n,
+                                                       uint32_t* __restrict__ ghist) {
+  __shared__ uint32_t hist[4][256];
+  const int tid = threadIdx.x;
+#pragma unroll
+  for (int p = 0; p < 4; p++) hist[p][tid] = 0;
+  __syncthreads();
+  const int ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const size_t base = (size_t)tile * SORT_TILE;
+    uint32_t key[SORT_TILE / 256];
+#pragma unroll
+    for (int s = 0; s < SORT_TILE / 256; s++) {
+      const size_t i = base + (size_t)s * 256 + tid;
+      key[s] = i < (size_t)n ? keys[i] : 0u;
+    }
+#pragma unroll
+    for (int s = 0; s < SORT_TILE / 256; s++) {
+      const size_t i = base + (size_t)s * 256 + tid;
+      if (i < (size_t)n) {
+        atomicAdd(&hist[0][key[s] & 255u], 1u);
+        atomicAdd(&hist[1][(key[s] >> 8) & 255u], 1u);
+        atomicAdd(&hist[2][(key[s] >> 16) & 255u], 1u);
+        atomicAdd(&hist[3][key[s] >> 24], 1u);
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const uint32_t c = hist[p][tid];
+    if (c) atomicAdd(&ghist[p * 256 + tid], c);
+  }
+}
+
+// Status word of one (tile, digit) in the single-launch-per-pass sort: bit 31 = inclusive prefix over tiles
+// [0, tile] known, bit 30 = only this tile's own count known, low 30 bits = the count.
+constexpr int LBK = 4;  // status words fetched per look-back round trip
+constexpr uint32_t ST_GLOBAL = 0x80000000u, ST_LOCAL = 0x40000000u, ST_MASK = 0x3FFFFFFFu;
+
+// LB = false: the classic pass -- digit offsets of every tile come from k_sort_hist / k_sort_scan_*.
+// LB = true: ONE launch per pass (decoupled look-back): a workgroup takes its tile from a ticket counter (so
+// every lower tile is already running), publishes its digit counts, and thread d walks back over the lower
+// tiles' status words of digit d until it meets a known prefix.  Used for the per-Gaussian depth sort, where
+// P / 4096 ~ 500 tiles make the three helper launches per pass cost more than the pass itself; for the
+// 10^7-instance tile sort the classic pass measured faster.
+template <typename K, bool LB>
 __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys_in,
                                                       const uint32_t* __restrict__ vals_in,
                                                       K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                       int n, int shift, int nbits, const uint32_t* __restrict__ counts,
                                                       const uint32_t* __restrict__ chunk_base,
-                                                      const uint32_t* __restrict__ digit_total) {
+                                                      const uint32_t* __restrict__ digit_total,
+                                                      uint32_t* __restrict__ status, uint32_t* __restrict__ ticket) {
   __shared__ uint32_t wcnt[4][256];  // per-wave digit counts, then per-wave local write bases
   __shared__ uint32_t gdelta[256];   // global position of local slot p holding digit d = gdelta[d] + p
   __shared__ uint32_t wtot[4];
   __shared__ K lkey[SORT_TILE];
   __shared__ uint32_t lval[SORT_TILE];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int tile = blockIdx.x;
+  int tile = blockIdx.x;
+  if (LB) {
+    __shared__ int s_tile;
+    if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
+    __syncthreads();
+    tile = s_tile;
+  }
   const uint32_t mask = (1u << nbits) - 1u;
   // global exclusive base of every digit (every workgroup recomputes it: 1 KB, L2-resident)
   const uint32_t dbase = block_excl_scan_256(digit_total[tid], lane, w, wtot);
@@ -149,6 +204,16 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys
     const bool valid = i < (size_t)n;
     key[s] = valid ? (uint32_t)keys_in[i] : 0u;
     val[s] = valid ? vals_in[i] : 0u;
+  }
+  if (LB) {  // publish this tile's digit counts as early as possible: the lower tiles' walks depend on them
+    gdelta[tid] = 0;
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < STEPS; s++)
+      if (base + (size_t)s * 64 + lane < (size_t)n) atomicAdd(&gdelta[(key[s] >> shift) & mask], 1u);
+    __syncthreads();
+    __hip_atomic_store(status + (size_t)tile * 256 + tid, (tile == 0 ? ST_GLOBAL : ST_LOCAL) | gdelta[tid],
+                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // pass A: rank of every element among the equal-digit elements of ITS WAVE that precede it
   volatile uint32_t* my = wcnt[w];
@@ -174,8 +239,45 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys
     wcnt[1][tid] = lbase + c0;
     wcnt[2][tid] = lbase + c0 + c1;
     wcnt[3][tid] = lbase + c0 + c1 + c2;
-    const int chunk = tile / SORT_CHUNK;
-    gdelta[tid] = dbase + chunk_base[(size_t)chunk * 256 + tid] + counts[(size_t)tile * 256 + tid] - lbase;
+    if (LB) {
+      const uint32_t c = c0 + c1 + c2 + c3;
+      uint32_t* mine = status + (size_t)tile * 256 + tid;
+      uint32_t excl = 0;
+      if (tile != 0) {
+        // walk back from tile - 1; tile 0 always ends the walk with a GLOBAL word.  LBK status words are
+        // fetched per round trip (independent loads) and consumed in order up to the first unpublished one.
+        int t = tile - 1;
+        bool done = false;
+        while (!done) {
+          uint32_t v[LBK];
+#pragma unroll
+          for (int k = 0; k < LBK; k++)
+            v[k] = t - k >= 0 ? __hip_atomic_load(status + (size_t)(t - k) * 256 + tid, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT)
+                              : 0u;
+          bool stalled = false;
+#pragma unroll
+          for (int k = 0; k < LBK; k++) {
+            if (done || stalled) continue;
+            if (v[k] & ST_GLOBAL) {
+              excl += v[k] & ST_MASK;
+              done = true;
+            } else if (v[k] & ST_LOCAL) {
+              excl += v[k] & ST_MASK;
+              t--;
+            } else {
+              stalled = true;  // not published yet: look again from here
+            }
+          }
+          if (stalled) __builtin_amdgcn_s_sleep(1);
+        }
+        __hip_atomic_store(mine, ST_GLOBAL | (excl + c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      gdelta[tid] = dbase + excl - lbase;
+    } else {
+      const int chunk = tile / SORT_CHUNK;
+      gdelta[tid] = dbase + chunk_base[(size_t)chunk * 256 + tid] + counts[(size_t)tile * 256 + tid] - lbase;
+    }
   }
   __syncthreads();
   // pass B: stable local reorder by digit
@@ -236,8 +338,8 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
     }
     {
       ProfScope ps(K_SORT_SCATTER + kb, s);
-      hipLaunchKernelGGL(k_sort_scatter<K>, dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n, shift, nbits,
-                         sc.counts, sc.chunk_sums, sc.digit_base);
+      hipLaunchKernelGGL((k_sort_scatter<K, false>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n, shift,
+                         nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr, (uint32_t*)nullptr);
     }
     inA = !inA;
   }
@@ -253,6 +355,29 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
     return sort_pairs_impl<uint16_t>(reinterpret_cast<uint16_t*>(keysA), valsA, reinterpret_cast<uint16_t*>(keysB),
                                      valsB, sc, n, end_bit, start_in_A, is_depth_sort, s);
   return sort_pairs_impl<uint32_t>(keysA, valsA, keysB, valsB, sc, n, end_bit, start_in_A, is_depth_sort, s);
+}
+
+// Depth sort of the P (depth bits, Gaussian id) pairs: 32-bit keys, four 8-bit passes, FIVE launches
+// (histograms of all digits, then one look-back scatter per pass).  Pairs start in (keysA, valsA) and end
+// there.  sc.words (ghist | tickets | status) must be zero on entry: k_preprocess clears it.
+hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
+                             int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  const int ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+  {
+    ProfScope ps(K_DSORT_HIST, s);
+    hipLaunchKernelGGL(k_sort_hist_all, dim3(ntiles < 256 ? ntiles : 256), dim3(256), 0, s, keysA, n, sc.ghist());
+  }
+  bool inA = true;
+  for (int p = 0; p < 4; p++) {
+    ProfScope ps(K_DSORT_SCATTER, s);
+    hipLaunchKernelGGL((k_sort_scatter<uint32_t, true>), dim3(ntiles), dim3(256), 0, s, inA ? keysA : keysB,
+                       inA ? valsA : valsB, inA ? keysB : keysA, inA ? valsB : valsA, n, 8 * p, 8,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
+                       sc.status(p, ntiles), sc.tickets() + p);
+    inA = !inA;
+  }
+  return hipGetLastError();
 }
 
 // Replaces identifyTileRanges (reference rasterizer_impl.cu:106-125); ranges must be zero beforehand (the

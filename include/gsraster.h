@@ -103,7 +103,8 @@ typedef struct gsr_geometry_view {
   const float* splats;            /* [P][12]: x, y, conic.x, conic.y, conic.z, opacity, r, g, b, depth, hx, hy */
   const float* cov3D;             /* [P][6]                               */
   const uint32_t* tiles_touched;  /* [P]                                  */
-  const uint32_t* point_offsets;  /* [P] inclusive scan                   */
+  const uint32_t* point_offsets;  /* [P] inclusive scan in id order (the reference's array; unused by this
+                                     pipeline: filled only when the forward ran with debug != 0) */
   const uint8_t* clamped;         /* [P] bit0..2 = r,g,b clamp flags      */
   const uint32_t* depth_order;    /* [P] Gaussian ids by (depth bits, id); culled Gaussians last */
 } gsr_geometry_view;
