@@ -22,6 +22,8 @@
 // (A single-pass decoupled-look-back variant -- tile tickets, per-digit status words, sc1 relaxed loads -- was
 // built and measured in round 1: correct, but 0.66 ms vs 0.51 ms for the tile sort at C3, so it was dropped;
 // see DESIGN.md "Tried and rejected".)
+#include <cstdlib>
+
 #include "gsr_internal.hpp"
 
 namespace gsr {
@@ -159,6 +161,35 @@ __global__ __launch_bounds__(256) void k_sort_hist_all(const uint32_t* __restric
   }
 }
 
+// Probe for the ARANK variant of k_sort_scatter: 1 = within one ds_add_rtn_u32 instruction, lanes that hit the
+// same LDS address receive their return values in ascending lane order (and successive instructions
+// accumulate), for 512 digit patterns covering every conflict multiplicity from 1 to 64.
+__global__ __launch_bounds__(64) void k_probe_lds_atomic_order(uint32_t* __restrict__ ok_out) {
+  __shared__ uint32_t hist[128];
+  const int lane = threadIdx.x;
+  volatile uint32_t* vh = hist;
+  bool ok = true;
+  for (uint32_t trial = 0; trial < 512; trial++) {
+    vh[lane] = 0;
+    vh[lane + 64] = 0;
+    // number of distinct digits: 1, 2, 4 .. 128, then pseudo-random in [1, 128]
+    const uint32_t groups = trial < 8 ? 1u << trial : 1u + ((trial * 2654435761u) >> 25);
+    for (uint32_t rep = 0; rep < 2; rep++) {  // the second instruction must continue from the first one's counts
+      uint32_t h = (uint32_t)lane * 0x9E3779B1u + trial * 0x85EBCA77u + rep * 0xC2B2AE3Du;
+      h ^= h >> 15; h *= 0x2C1B3C6Du; h ^= h >> 12;
+      // odd trials: scattered digits; even trials: runs of equal digits in neighbouring lanes
+      const uint32_t run = 64u / (groups > 64u ? 64u : groups);
+      const uint32_t d = ((trial & 1u) ? h : (uint32_t)lane / run + rep) % groups;
+      const uint64_t m = match_digit(d, true, 7);
+      const uint32_t before = vh[d];  // LDS operations of one wave execute in issue order
+      const uint32_t got = __hip_atomic_fetch_add(&hist[d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (got != before + (uint32_t)__popcll(m & lanemask_lt(lane))) ok = false;
+    }
+  }
+  const uint64_t all = __ballot(ok);
+  if (lane == 0) *ok_out = all == ~0ull ? 1u : 0u;
+}
+
 // Status word of one (tile, digit) in the single-launch-per-pass sort: bit 31 = inclusive prefix over tiles
 // [0, tile] known, bit 30 = only this tile's own count known, low 30 bits = the count.
 constexpr int LBK = 4;  // status words fetched per look-back round trip
@@ -170,7 +201,7 @@ constexpr uint32_t ST_GLOBAL = 0x80000000u, ST_LOCAL = 0x40000000u, ST_MASK = 0x
 // tiles' status words of digit d until it meets a known prefix.  Used for the per-Gaussian depth sort, where
 // P / 4096 ~ 500 tiles make the three helper launches per pass cost more than the pass itself; for the
 // 10^7-instance tile sort the classic pass measured faster.
-template <typename K, bool LB>
+template <typename K, bool LB, bool ARANK>
 __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys_in,
                                                       const uint32_t* __restrict__ vals_in,
                                                       K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -222,6 +253,15 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys
     const size_t i = base + (size_t)s * 64 + lane;
     const bool valid = i < (size_t)n;
     const uint32_t d = (key[s] >> shift) & mask;
+    if (ARANK) {
+      // One returning LDS add per step does the whole job of the ballot match below: the value returned to a lane
+      // is the number of equal-digit elements of this wave that precede it, PROVIDED the LDS resolves the lanes
+      // of one instruction that hit the same address in ascending lane order.  That order is not in the ISA
+      // manual, so the host probes it once per process (k_probe_lds_atomic_order) and only then selects this
+      // variant; the parity suite additionally checks the sorted lists bit for bit.  -17 % on the tile sort.
+      lrank[s] = valid ? __hip_atomic_fetch_add(&wcnt[w][d], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+      continue;
+    }
     const uint64_t m = match_digit(d, valid, nbits);
     const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt(lane));
     const uint32_t prior = my[d];  // same address inside a digit group: LDS broadcast
@@ -307,6 +347,23 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys
   }
 }
 
+// Once per process: may k_sort_scatter rank with returning LDS atomics (see ARANK)?  GSR_SORT_BALLOT_RANK=1 in
+// the environment forces the ballot variant.
+static bool lds_atomic_rank_ok(hipStream_t s) {
+  static int state = -1;
+  if (state >= 0) return state == 1;
+  state = 0;
+  if (getenv("GSR_SORT_BALLOT_RANK")) return false;
+  uint32_t* d = nullptr;
+  uint32_t h = 0;
+  if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(uint32_t)) != hipSuccess) return false;
+  hipLaunchKernelGGL(k_probe_lds_atomic_order, dim3(1), dim3(64), 0, s, d);
+  if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
+    state = h == 1u ? 1 : 0;
+  (void)hipFree(d);
+  return state == 1;
+}
+
 // The pairs start in (keysA, valsA) when start_in_A, else in (keysB, valsB); passes alternate.  The caller
 // picks start_in_A = (passes even) so the result always lands in (keysA, valsA).
 template <typename K>
@@ -317,6 +374,7 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
   const int nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
   const int passes = sort_passes(end_bit);
   const int nbits = sort_digit_bits(end_bit);
+  const bool arank = lds_atomic_rank_ok(s);
   bool inA = start_in_A;
   for (int p = 0; p < passes; p++) {
     const K* kin = inA ? keysA : keysB;
@@ -338,8 +396,14 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
     }
     {
       ProfScope ps(K_SORT_SCATTER + kb, s);
-      hipLaunchKernelGGL((k_sort_scatter<K, false>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n, shift,
-                         nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr, (uint32_t*)nullptr);
+      if (arank)
+        hipLaunchKernelGGL((k_sort_scatter<K, false, true>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
+                           shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr);
+      else
+        hipLaunchKernelGGL((k_sort_scatter<K, false, false>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
+                           shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr);
     }
     inA = !inA;
   }
@@ -368,13 +432,22 @@ hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
     ProfScope ps(K_DSORT_HIST, s);
     hipLaunchKernelGGL(k_sort_hist_all, dim3(ntiles < 256 ? ntiles : 256), dim3(256), 0, s, keysA, n, sc.ghist());
   }
+  const bool arank = lds_atomic_rank_ok(s);
   bool inA = true;
   for (int p = 0; p < 4; p++) {
     ProfScope ps(K_DSORT_SCATTER, s);
-    hipLaunchKernelGGL((k_sort_scatter<uint32_t, true>), dim3(ntiles), dim3(256), 0, s, inA ? keysA : keysB,
-                       inA ? valsA : valsB, inA ? keysB : keysA, inA ? valsB : valsA, n, 8 * p, 8,
-                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
-                       sc.status(p, ntiles), sc.tickets() + p);
+    const uint32_t* kin = inA ? keysA : keysB;
+    const uint32_t* vin = inA ? valsA : valsB;
+    uint32_t* kout = inA ? keysB : keysA;
+    uint32_t* vout = inA ? valsB : valsA;
+    if (arank)
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
+                         8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
+                         sc.status(p, ntiles), sc.tickets() + p);
+    else
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout,
+                         n, 8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
+                         sc.status(p, ntiles), sc.tickets() + p);
     inA = !inA;
   }
   return hipGetLastError();
