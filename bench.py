@@ -89,9 +89,12 @@ def main():
     ap.add_argument("--loss", default="seeded", choices=("seeded", "photometric"),
                     help="seeded: inject the fixed upstream gradients of SURVEY.md 8(d); photometric: the reference's "
                          "0.8*L1 + 0.2*(1-SSIM) against a fixed random target (fused HIP loss kernels)")
-    ap.add_argument("--sync-mode", default="allreduce", choices=("allreduce", "owner"),
-                    help="N > 1: 'allreduce' = sum the per-view gradients on every rank and step replicated Adam "
-                         "(one collective per step); 'owner' = reduce to rank 0, Adam there, broadcast the parameters")
+    ap.add_argument("--sync-mode", default="scatter", choices=("scatter", "allreduce", "owner"),
+                    help="N > 1: 'scatter' (BASELINE C4 as worded: independent views, RCCL only scatters the shared "
+                         "Gaussian buffer -- one broadcast from rank 0 before the loop, no collective per step); "
+                         "'allreduce' = joint optimisation of all views: sum the per-view gradients on every rank and "
+                         "step replicated Adam (one 56 B/Gaussian collective per step); 'owner' = reduce to rank 0, "
+                         "Adam there, broadcast the parameters (two collectives per step)")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = rehearsal of the multi-rank control flow (collectives staged through the host)")
     args = ap.parse_args()
@@ -136,7 +139,8 @@ def main():
                                  v["opacities"])
     leaves = dict(means3D=model._xyz, features_dc=model._features_dc, features_rest=model._features_rest,
                   scales=model._scaling, rotations=model._rotation, opacities=model._opacity)
-    flat_grads = n_gpus > 1  # one flat gradient buffer = one collective; a single GPU lets autograd hand over its
+    joint = n_gpus > 1 and args.sync_mode != "scatter"  # views optimised jointly: gradients are exchanged
+    flat_grads = joint   # one flat gradient buffer = one collective; otherwise autograd hands over its
     if flat_grads:           # gradient tensors as they are (no accumulate kernels, nothing to zero)
         for k, p in leaves.items():
             p.grad = grads.views[k]
@@ -176,7 +180,7 @@ def main():
                     torch.cat([model._features_dc, model._features_rest], 1))
         return model.activated()
 
-    owner_mode = n_gpus > 1 and args.sync_mode == "owner"
+    owner_mode = joint and args.sync_mode == "owner"
 
     def step():
         if owner_mode:
@@ -194,7 +198,7 @@ def main():
             G.photometric_loss(color, target, 0.2, window).backward()
         else:  # upstream gradients injected directly (SURVEY.md 8(d) backward seeds): dL/dcolor = wc, dL/dacc = wa
             torch.autograd.backward([color, acc], [wc, wa])
-        if n_gpus > 1:
+        if joint:
             MV.reduce_gradients(grads, dst=0, all_ranks=not owner_mode)
         if not args.no_adam and (rank == 0 or not owner_mode):
             if args.torch_optimizer:

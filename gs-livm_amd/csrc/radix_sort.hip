@@ -28,8 +28,6 @@
 
 namespace gsr {
 
-constexpr int WAVE_TILE = SORT_TILE / 4;  // 1024
-constexpr int STEPS = WAVE_TILE / 64;     // 16
 
 __device__ __forceinline__ uint64_t lanemask_lt(int lane) { return (1ull << lane) - 1ull; }
 
@@ -192,6 +190,7 @@ __global__ __launch_bounds__(64) void k_probe_lds_atomic_order(uint32_t* __restr
 
 // Status word of one (tile, digit) in the single-launch-per-pass sort: bit 31 = inclusive prefix over tiles
 // [0, tile] known, bit 30 = only this tile's own count known, low 30 bits = the count.
+constexpr int TSORT_WAVES = 4;  // waves per workgroup in the tile sort's scatter pass (8 measured 5 % slower)
 constexpr int LBK = 4;  // status words fetched per look-back round trip
 constexpr uint32_t ST_GLOBAL = 0x80000000u, ST_LOCAL = 0x40000000u, ST_MASK = 0x3FFFFFFFu;
 
@@ -201,17 +200,21 @@ constexpr uint32_t ST_GLOBAL = 0x80000000u, ST_LOCAL = 0x40000000u, ST_MASK = 0x
 // tiles' status words of digit d until it meets a known prefix.  Used for the per-Gaussian depth sort, where
 // P / 4096 ~ 500 tiles make the three helper launches per pass cost more than the pass itself; for the
 // 10^7-instance tile sort the classic pass measured faster.
-template <typename K, bool LB, bool ARANK>
-__global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys_in,
+// NW = waves per workgroup (4 or 8) sharing one 4096-pair tile.  With returning-atomic ranking VALU issue is only
+// 12 % of the pass (SQ counters) and 8 waves (twice the loads in flight per CU) did not help: at 331 MB algorithmic /
+// 380 MB measured traffic in 95 us the pass moves ~4 TB/s of mixed reads and 64-128-byte write runs.
+template <typename K, bool LB, bool ARANK, int NW>
+__global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ keys_in,
                                                       const uint32_t* __restrict__ vals_in,
                                                       K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                       int n, int shift, int nbits, const uint32_t* __restrict__ counts,
                                                       const uint32_t* __restrict__ chunk_base,
                                                       const uint32_t* __restrict__ digit_total,
                                                       uint32_t* __restrict__ status, uint32_t* __restrict__ ticket) {
-  __shared__ uint32_t wcnt[4][256];  // per-wave digit counts, then per-wave local write bases
-  __shared__ uint32_t gdelta[256];   // global position of local slot p holding digit d = gdelta[d] + p
-  __shared__ uint32_t wtot[4];
+  constexpr int NT = 64 * NW, WTILE = SORT_TILE / NW, NSTEP = WTILE / 64;
+  __shared__ uint32_t wcnt[NW][256];  // per-wave digit counts, then per-wave local write bases
+  __shared__ uint32_t gdelta[256];    // global position of local slot p holding digit d = gdelta[d] + p
+  __shared__ uint32_t wtot[NW];
   __shared__ K lkey[SORT_TILE];
   __shared__ uint32_t lval[SORT_TILE];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -224,32 +227,33 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys
   }
   const uint32_t mask = (1u << nbits) - 1u;
   // global exclusive base of every digit (every workgroup recomputes it: 1 KB, L2-resident)
-  const uint32_t dbase = block_excl_scan_256(digit_total[tid], lane, w, wtot);
+  const uint32_t dbase = block_excl_scan_256(tid < 256 ? digit_total[tid] : 0u, lane, w, wtot);  // waves >= 4: unused
 #pragma unroll
   for (int k = 0; k < 4; k++) wcnt[w][lane + 64 * k] = 0;
-  const size_t base = (size_t)tile * SORT_TILE + (size_t)w * WAVE_TILE;
-  uint32_t key[STEPS], val[STEPS], lrank[STEPS];
+  const size_t base = (size_t)tile * SORT_TILE + (size_t)w * WTILE;
+  uint32_t key[NSTEP], val[NSTEP], lrank[NSTEP];
 #pragma unroll
-  for (int s = 0; s < STEPS; s++) {
+  for (int s = 0; s < NSTEP; s++) {
     const size_t i = base + (size_t)s * 64 + lane;
     const bool valid = i < (size_t)n;
     key[s] = valid ? (uint32_t)keys_in[i] : 0u;
     val[s] = valid ? vals_in[i] : 0u;
   }
   if (LB) {  // publish this tile's digit counts as early as possible: the lower tiles' walks depend on them
-    gdelta[tid] = 0;
+    if (tid < 256) gdelta[tid] = 0;
     __syncthreads();
 #pragma unroll
-    for (int s = 0; s < STEPS; s++)
+    for (int s = 0; s < NSTEP; s++)
       if (base + (size_t)s * 64 + lane < (size_t)n) atomicAdd(&gdelta[(key[s] >> shift) & mask], 1u);
     __syncthreads();
-    __hip_atomic_store(status + (size_t)tile * 256 + tid, (tile == 0 ? ST_GLOBAL : ST_LOCAL) | gdelta[tid],
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid < 256)
+      __hip_atomic_store(status + (size_t)tile * 256 + tid, (tile == 0 ? ST_GLOBAL : ST_LOCAL) | gdelta[tid],
+                         __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   // pass A: rank of every element among the equal-digit elements of ITS WAVE that precede it
   volatile uint32_t* my = wcnt[w];
 #pragma unroll
-  for (int s = 0; s < STEPS; s++) {
+  for (int s = 0; s < NSTEP; s++) {
     const size_t i = base + (size_t)s * 64 + lane;
     const bool valid = i < (size_t)n;
     const uint32_t d = (key[s] >> shift) & mask;
@@ -273,14 +277,21 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys
   __syncthreads();
   // per digit (thread = digit): tile-local base (exclusive over digits), per-wave bases, global delta
   {
-    const uint32_t c0 = wcnt[0][tid], c1 = wcnt[1][tid], c2 = wcnt[2][tid], c3 = wcnt[3][tid];
-    const uint32_t lbase = block_excl_scan_256(c0 + c1 + c2 + c3, lane, w, wtot);
-    wcnt[0][tid] = lbase;
-    wcnt[1][tid] = lbase + c0;
-    wcnt[2][tid] = lbase + c0 + c1;
-    wcnt[3][tid] = lbase + c0 + c1 + c2;
+    uint32_t cw[NW], c = 0;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      cw[k] = tid < 256 ? wcnt[k][tid] : 0u;
+      c += cw[k];
+    }
+    const uint32_t lbase = block_excl_scan_256(c, lane, w, wtot);  // barriers inside: every thread calls it
+    if (tid < 256) {
+    uint32_t run = lbase;
+#pragma unroll
+    for (int k = 0; k < NW; k++) {
+      wcnt[k][tid] = run;
+      run += cw[k];
+    }
     if (LB) {
-      const uint32_t c = c0 + c1 + c2 + c3;
       uint32_t* mine = status + (size_t)tile * 256 + tid;
       uint32_t excl = 0;
       if (tile != 0) {
@@ -318,11 +329,12 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys
       const int chunk = tile / SORT_CHUNK;
       gdelta[tid] = dbase + chunk_base[(size_t)chunk * 256 + tid] + counts[(size_t)tile * 256 + tid] - lbase;
     }
+    }
   }
   __syncthreads();
   // pass B: stable local reorder by digit
 #pragma unroll
-  for (int s = 0; s < STEPS; s++) {
+  for (int s = 0; s < NSTEP; s++) {
     const size_t i = base + (size_t)s * 64 + lane;
     if (i < (size_t)n) {
       const uint32_t d = (key[s] >> shift) & mask;
@@ -336,8 +348,8 @@ __global__ __launch_bounds__(256) void k_sort_scatter(const K* __restrict__ keys
   const size_t tile_base = (size_t)tile * SORT_TILE;
   const uint32_t nvalid = (size_t)n - tile_base < (size_t)SORT_TILE ? (uint32_t)((size_t)n - tile_base) : SORT_TILE;
 #pragma unroll
-  for (int k = 0; k < SORT_TILE / 256; k++) {
-    const uint32_t p = (uint32_t)(k * 256 + tid);
+  for (int k = 0; k < SORT_TILE / NT; k++) {
+    const uint32_t p = (uint32_t)(k * NT + tid);
     if (p < nvalid) {
       const uint32_t kk = (uint32_t)lkey[p];
       const uint32_t g = gdelta[(kk >> shift) & mask] + p;
@@ -397,11 +409,11 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
     {
       ProfScope ps(K_SORT_SCATTER + kb, s);
       if (arank)
-        hipLaunchKernelGGL((k_sort_scatter<K, false, true>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
+        hipLaunchKernelGGL((k_sort_scatter<K, false, true, TSORT_WAVES>), dim3(ntiles), dim3(64 * TSORT_WAVES), 0, s, kin, vin, kout, vout, n,
                            shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
       else
-        hipLaunchKernelGGL((k_sort_scatter<K, false, false>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
+        hipLaunchKernelGGL((k_sort_scatter<K, false, false, 4>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
                            shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
     }
@@ -441,11 +453,11 @@ hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
     uint32_t* kout = inA ? keysB : keysA;
     uint32_t* vout = inA ? valsB : valsA;
     if (arank)
-      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true, 4>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
                          8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     else
-      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout,
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false, 4>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout,
                          n, 8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     inA = !inA;
