@@ -16,7 +16,8 @@ from . import multiview, synthetic  # noqa: F401
 from ._capi import (GsrError, LIB_PATH, lib, mark_visible, profile_enable, profile_read,  # noqa: F401
                     rasterize_backward, rasterize_forward, state_views)
 from .loss import PhotometricLoss, photometric_loss, reference_window_1d  # noqa: F401
-from .model import FusedActivations, FusedAdam, GaussianParameters  # noqa: F401
+from .model import FusedActivations, FusedAdam, GaussianParameters, GrowableAdam, GrowableGaussians  # noqa: F401
+from . import ply  # noqa: F401
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,  # noqa: F401
                          rasterize_gaussians)
 
@@ -38,5 +39,5 @@ def torch_ops():
     return mod
 
 
-__all__ = ["PhotometricLoss", "photometric_loss", "reference_window_1d", "FusedActivations", "FusedAdam", "GaussianParameters", "GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_forward",
+__all__ = ["PhotometricLoss", "photometric_loss", "reference_window_1d", "FusedActivations", "FusedAdam", "GaussianParameters", "GrowableAdam", "GrowableGaussians", "ply", "GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_forward",
            "rasterize_backward", "mark_visible", "state_views", "lib", "torch_ops", "synthetic", "multiview", "GsrError", "LIB_PATH"]

@@ -35,7 +35,8 @@ EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_byte
            "gsr_binning_bytes", "gsr_geometry_view_of", "gsr_binning_view_of", "gsr_image_view_of",
            "gsr_higher_msb", "gsr_last_error", "gsr_abi_version", "gsr_kernel_count", "gsr_kernel_name",
            "gsr_profile_enable", "gsr_profile_enable_only", "gsr_profile_read", "gsr_activate", "gsr_activate_backward", "gsr_adam_step",
-           "gsr_photometric_loss", "gsr_photometric_loss_workspace")
+           "gsr_photometric_loss", "gsr_photometric_loss_workspace", "gsr_init_gaussians", "gsr_ply_row_floats",
+           "gsr_pack_ply_rows")
 
 
 def lib():
@@ -84,6 +85,12 @@ def lib():
     L.gsr_photometric_loss_workspace.argtypes = [ci, ci, ci]
     L.gsr_photometric_loss.restype = ci
     L.gsr_photometric_loss.argtypes = [ci, ci, ci, vp, vp, C.POINTER(cf), cf, vp, vp, vp, sz, vp]
+    L.gsr_init_gaussians.restype = ci
+    L.gsr_init_gaussians.argtypes = [ci, ci, vp, vp, vp, cf] + [vp] * 6 + [vp]
+    L.gsr_ply_row_floats.restype = sz
+    L.gsr_ply_row_floats.argtypes = [ci]
+    L.gsr_pack_ply_rows.restype = ci
+    L.gsr_pack_ply_rows.argtypes = [ci, ci] + [vp] * 7 + [vp]
     L.gsr_adam_step.restype = ci
     L.gsr_adam_step.argtypes = [ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz),
                                 C.POINTER(cf), cf, cf, cf, ci, ci, vp]
@@ -321,3 +328,29 @@ def photometric_loss(img, gt, window11, lambda_dssim, want_grad=True):
     _check(lib().gsr_photometric_loss(Cn, H, W, _ptr(img), _ptr(gt), win, float(lambda_dssim), _ptr(out3), _ptr(grad),
                                       _ptr(ws), nbytes, _stream()))
     return out3, grad
+
+
+# ---- "next" row 4: map growth and PLY export (include/gsraster.h; csrc/growth.hip) ----
+def init_gaussians(xyz, covs, rgbs, scale_factor, out_xyz, out_features_dc, out_features_rest, out_scaling,
+                   out_rotation, out_opacity):
+    """GaussianModel::addNewPointcloud's arithmetic (src/gs/gaussian.cu:241-313) for n new points, written in
+    place into the given (contiguous, n-row) output views -- normally the tail rows of capacity buffers."""
+    n = int(xyz.size(0))
+    M = 1 + (int(out_features_rest.size(1)) if out_features_rest is not None and out_features_rest.numel() else 0)
+    for t in (xyz, covs, rgbs, out_xyz, out_features_dc, out_scaling, out_rotation, out_opacity):
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+    assert covs.shape == (n, 3, 3) and rgbs.shape == (n, 3)
+    _check(lib().gsr_init_gaussians(n, M, _ptr(xyz), _ptr(covs), _ptr(rgbs), float(scale_factor), _ptr(out_xyz),
+                                    _ptr(out_features_dc), _ptr(out_features_rest), _ptr(out_scaling),
+                                    _ptr(out_rotation), _ptr(out_opacity), _stream()))
+
+
+def pack_ply_rows(xyz, features_dc, features_rest, opacity, scaling, rotation):
+    """[P, 14 + 3M] f32 device tensor: the vertex rows of the reference's PLY export (one coalesced pass)."""
+    P = int(xyz.size(0))
+    M = 1 + (int(features_rest.size(1)) if features_rest is not None and features_rest.numel() else 0)
+    rf = int(lib().gsr_ply_row_floats(M))
+    rows = torch.empty((P, rf), dtype=torch.float32, device=xyz.device)
+    args = [t.contiguous() for t in (xyz, features_dc, features_rest, opacity, scaling, rotation)]
+    _check(lib().gsr_pack_ply_rows(P, M, *[_ptr(t) for t in args], _ptr(rows), _stream()))
+    return rows

@@ -31,6 +31,7 @@ UNITS = {
     "render.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"] + os.environ.get("GSR_EXTRA_RENDER_FLAGS", "").split(),
     "optimizer.hip": [],
     "loss.hip": [],
+    "growth.hip": [],
     "api.hip": [],
 }
 HEADERS = [os.path.join(CSRC, "gsr_internal.hpp"), os.path.join(ROOT, "include", "gsraster.h")]

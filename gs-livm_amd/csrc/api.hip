@@ -63,7 +63,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top", "k_sort_scatter", "k_tile_ranges", "k_blend_forward",
     "k_blend_backward", "k_compact_touched", "k_gather_records", "k_gaussian_backward", "k_mark_visible", "k_sort_hist[depth]",
     "k_sort_scan_chunks[depth]", "k_sort_scan_top[depth]", "k_sort_scatter[depth]", "k_activate",
-    "k_activate_backward", "k_adam", "k_loss_forward", "k_loss_finalize", "k_loss_backward"};
+    "k_activate_backward", "k_adam", "k_loss_forward", "k_loss_finalize", "k_loss_backward", "k_init_gaussians", "k_pack_ply_rows"};
 
 extern "C" {
 
@@ -382,6 +382,34 @@ int gsr_photometric_loss(int channels, int height, int width, const float* img, 
                 loss_workspace_bytes(channels, height, width));
   HIP_TRY(launch_photometric_loss(channels, height, width, img, gt, window11_host, lambda_dssim, loss_out3, dL_dimg,
                                   workspace, (hipStream_t)stream_));
+  return GSR_OK;
+}
+
+int gsr_init_gaussians(int n, int M, const float* xyz, const float* covs, const float* rgbs, float scale_factor,
+                       float* xyz_out, float* features_dc_out, float* features_rest_out, float* scaling_out,
+                       float* rotation_out, float* opacity_out, void* stream_) {
+  g_err[0] = 0;
+  if (n < 0 || M < 1 || M > 16) return fail(GSR_ERR_INVALID_ARGUMENT, "bad n/M");
+  if (n == 0) return GSR_OK;
+  if (!xyz || !covs || !rgbs || !xyz_out || !features_dc_out || (M > 1 && !features_rest_out) || !scaling_out ||
+      !rotation_out || !opacity_out)
+    return fail(GSR_ERR_INVALID_ARGUMENT, "null pointer");
+  HIP_TRY(launch_init_gaussians(n, M, xyz, covs, rgbs, scale_factor, xyz_out, features_dc_out, features_rest_out,
+                                scaling_out, rotation_out, opacity_out, (hipStream_t)stream_));
+  return GSR_OK;
+}
+
+size_t gsr_ply_row_floats(int M) { return M >= 1 ? (size_t)(14 + 3 * M) : 0; }
+
+int gsr_pack_ply_rows(int P, int M, const float* xyz, const float* features_dc, const float* features_rest,
+                      const float* opacity, const float* scaling, const float* rotation, float* rows, void* stream_) {
+  g_err[0] = 0;
+  if (P < 0 || M < 1 || M > 16) return fail(GSR_ERR_INVALID_ARGUMENT, "bad P/M");
+  if (P == 0) return GSR_OK;
+  if (!xyz || !features_dc || (M > 1 && !features_rest) || !opacity || !scaling || !rotation || !rows)
+    return fail(GSR_ERR_INVALID_ARGUMENT, "null pointer");
+  HIP_TRY(launch_pack_ply_rows(P, M, xyz, features_dc, features_rest, opacity, scaling, rotation, rows,
+                               (hipStream_t)stream_));
   return GSR_OK;
 }
 

@@ -6,7 +6,10 @@ kernels of csrc/optimizer.hip (SURVEY.md section 8(f) "next" row 1):
   * `GaussianParameters` -- the six leaf tensors with those getter names;
   * `FusedAdam` -- torch::optim::Adam as the reference configures it (src/gs/gaussian.cu:396-428: one group
     per leaf, eps 1e-15, betas (0.9, 0.999), no weight decay) stepping every group in one launch and clearing
-    the gradients it consumed (step + zero_grad, src/liw/lioOptimization.cpp:1831-1832).
+    the gradients it consumed (step + zero_grad, src/liw/lioOptimization.cpp:1831-1832);
+  * `GrowableGaussians` -- row 4: the model as capacity buffers that grow in place
+    (GaussianModel::addNewPointcloud / densification_postfix / cat_tensors_to_optimizer,
+    src/gs/gaussian.cu:241-313, 451-472, 524-540).
 """
 import torch
 
@@ -107,3 +110,91 @@ class FusedAdam(torch.optim.Optimizer):
         for i in range(0, len(ps), 8):
             _capi.adam_step(ps[i:i + 8], gs[i:i + 8], ms[i:i + 8], vs[i:i + 8], lrs[i:i + 8], betas[0], betas[1],
                             eps, self._step, zero_grads)
+
+
+class GrowableGaussians(GaussianParameters):
+    """The six leaves and their Adam moments as CAPACITY buffers; the leaves are views of the first P rows.
+
+    The reference grows the map every few frames by building the new rows with Torch ops and then
+    `torch::cat`-ing ALL six parameter tensors and all twelve optimiser-state tensors (whole-model copies,
+    src/gs/gaussian.cu:451-472, 524-540).  Here `add_new_pointcloud` initialises rows [P, P + n) in place with
+    one kernel (csrc/growth.hip) and re-binds the leaves: O(n) bytes move; the moments of the new rows are the
+    zeros the buffers were created with (= the reference's `zeros_like(extension_tensor)`), the step count is
+    shared (= the reference keeps the old AdamParamState's step).  When the capacity is exhausted the buffers
+    double (one amortised copy).
+    """
+
+    _NAMES = ("_xyz", "_features_dc", "_features_rest", "_scaling", "_rotation", "_opacity")
+
+    def __init__(self, capacity, M, device):
+        torch.nn.Module.__init__(self)
+        self.M, self.P, self.capacity, self.device = int(M), 0, 0, torch.device(device)
+        self._buf, self._m, self._v = {}, {}, {}
+        self._optimizer = None
+        self._reserve(max(1, int(capacity)))
+        self._bind()
+
+    def _shapes(self):
+        return {"_xyz": (3,), "_features_dc": (1, 3), "_features_rest": (self.M - 1, 3), "_scaling": (3,),
+                "_rotation": (4,), "_opacity": (1,)}
+
+    def _reserve(self, capacity):
+        for name, tail in self._shapes().items():
+            for store in (self._buf, self._m, self._v):
+                new = torch.zeros((capacity,) + tail, dtype=torch.float32, device=self.device)
+                if name in store and self.P:
+                    new[:self.P].copy_(store[name][:self.P])
+                store[name] = new
+        self.capacity = capacity
+
+    def _bind(self):
+        """Leaves = views of the first P rows (new Parameter objects, same storage); optimiser state follows."""
+        for name in self._NAMES:
+            setattr(self, name, torch.nn.Parameter(self._buf[name][:self.P]))
+        if self._optimizer is not None:
+            self._optimizer.rebind(self)
+
+    def moments(self, name):
+        return self._m[name][:self.P], self._v[name][:self.P]
+
+    def attach(self, optimizer):
+        self._optimizer = optimizer
+
+    @torch.no_grad()
+    def add_new_pointcloud(self, xyz, covs, rgbs, scale_factor=1.0):
+        """GaussianModel::addNewPointcloud (src/gs/gaussian.cu:241-313): xyz [n,3], covs [n,3,3], rgbs [n,3] (0..255),
+        device f32.  Returns the row range of the new Gaussians."""
+        n = int(xyz.size(0))
+        if n == 0:
+            return self.P, self.P
+        if self.P + n > self.capacity:
+            self._reserve(max(2 * self.capacity, self.P + n))
+        lo, hi = self.P, self.P + n
+        b = self._buf
+        _capi.init_gaussians(xyz.contiguous(), covs.contiguous(), rgbs.contiguous(), scale_factor, b["_xyz"][lo:hi],
+                             b["_features_dc"][lo:hi], b["_features_rest"][lo:hi], b["_scaling"][lo:hi],
+                             b["_rotation"][lo:hi], b["_opacity"][lo:hi])
+        self.P = hi
+        self._bind()
+        return lo, hi
+
+
+class GrowableAdam(FusedAdam):
+    """FusedAdam whose moments live in the model's capacity buffers, so growing the model needs no optimiser-state
+    concatenation (cat_tensors_to_optimizer, src/gs/gaussian.cu:451-472)."""
+
+    def __init__(self, model, eps=1e-15, **lrs):
+        self._lrs = lrs
+        super().__init__(model.param_groups(**lrs), eps=eps)
+        model.attach(self)
+        self.rebind(model)
+
+    def rebind(self, model):
+        groups = model.param_groups(**self._lrs)
+        for g_old, g_new in zip(self.param_groups, groups):
+            g_old["params"] = g_new["params"]
+        self.state.clear()
+        for name in model._NAMES:
+            p = getattr(model, name)
+            m, v = model.moments(name)
+            self.state[p] = {"exp_avg": m, "exp_avg_sq": v}

@@ -164,6 +164,26 @@ int gsr_photometric_loss(int channels, int height, int width, const float* img, 
                          const float* window11_host, float lambda_dssim, float* loss_out3, float* dL_dimg,
                          char* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- "next" row: the data formats either side of the path ----
+ * gsr_init_gaussians: new map points -> leaf parameter rows, the arithmetic of GaussianModel::addNewPointcloud
+ * (src/gs/gaussian.cu:241-313): _xyz = xyz; _scaling = log(sqrt(diag(cov) * scale_factor)) (decomposeSR keeps the
+ * diagonal, :10-11, 276-281); _rotation = (1, 0, 0, 0); _opacity = inverse_sigmoid(0.5) = 0;
+ * _features_dc[.][0][c] = (rgb_c / 255 - 0.5) / C0; _features_rest = 0.  covs [n][3][3], rgbs [n][3] in 0..255.
+ * The *_out pointers address row `P_old` of the caller's capacity buffers: rows are initialised in place, so
+ * growing the map moves O(n) bytes instead of re-concatenating all six tensors and their Adam moments
+ * (densification_postfix / cat_tensors_to_optimizer, :451-472, 524-540).
+ * gsr_pack_ply_rows: the vertex rows of the reference's PLY export (construct_list_of_attributes :474-492,
+ * Save_ply :494-522): per Gaussian gsr_ply_row_floats(M) = 14 + 3M little-endian f32 --
+ *   x y z | nx ny nz (zeros) | f_dc_0..2 | f_rest_0..3(M-1)-1 | opacity | scale_0..2 | rot_0..3
+ * with f_dc / f_rest in the reference's transpose(1,2).flatten(1) (channel-major) order.  rows: device buffer of
+ * P * (14 + 3M) floats; the host copies it once and writes header + rows (gs-livm_amd/ply.py). */
+int gsr_init_gaussians(int n, int M, const float* xyz, const float* covs, const float* rgbs, float scale_factor,
+                       float* xyz_out, float* features_dc_out, float* features_rest_out, float* scaling_out,
+                       float* rotation_out, float* opacity_out, void* stream);
+size_t gsr_ply_row_floats(int M);
+int gsr_pack_ply_rows(int P, int M, const float* xyz, const float* features_dc, const float* features_rest,
+                      const float* opacity, const float* scaling, const float* rotation, float* rows, void* stream);
+
 /* Optional per-kernel device timing (hipEvent pairs recorded on the launch stream around every
  * kernel launch while enabled).  Measurement aid for bench.py's roofline line; the reference has only
  * host wall-clock timers (include/common/timer/timer.h:36-52).  Not thread-safe; off by default.
