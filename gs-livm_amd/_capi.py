@@ -93,7 +93,7 @@ def lib():
     L.gsr_pack_ply_rows.argtypes = [ci, ci] + [vp] * 7 + [vp]
     L.gsr_adam_step.restype = ci
     L.gsr_adam_step.argtypes = [ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz),
-                                C.POINTER(cf), cf, cf, cf, ci, ci, vp]
+                                C.POINTER(cf), C.c_double, C.c_double, C.c_double, ci, ci, vp]
     _lib = L
     return L
 

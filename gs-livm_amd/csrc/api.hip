@@ -351,7 +351,7 @@ int gsr_activate_backward(int P, int M, const float* rotation_raw, const float* 
 }
 
 int gsr_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
-                  float* const* exp_avg_sq, const size_t* numel, const float* lr, float beta1, float beta2, float eps,
+                  float* const* exp_avg_sq, const size_t* numel, const float* lr, double beta1, double beta2, double eps,
                   int step, int zero_grads, void* stream_) {
   g_err[0] = 0;
   if (n_tensors < 0 || n_tensors > 8) return fail(GSR_ERR_INVALID_ARGUMENT, "1..8 tensors per call");

@@ -247,8 +247,8 @@ hipError_t launch_pack_ply_rows(int P, int M, const float* xyz, const float* fdc
                                 const float* opacity, const float* scaling, const float* rotation, float* rows,
                                 hipStream_t s);
 hipError_t launch_adam(int n, float* const* params, float* const* grads, float* const* exp_avg,
-                       float* const* exp_avg_sq, const size_t* numel, const float* lr, float beta1, float beta2,
-                       float eps, int step, int zero_grads, hipStream_t s);
+                       float* const* exp_avg_sq, const size_t* numel, const float* lr, double beta1, double beta2,
+                       double eps, int step, int zero_grads, hipStream_t s);
 
 inline int sort_passes(int end_bit) { return (end_bit + 7) / 8; }
 // digit width: the key bits are split evenly over the passes (13 tile bits -> 7 + 6, 32 depth bits -> 4 x 8)

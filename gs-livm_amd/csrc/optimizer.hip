@@ -87,15 +87,15 @@ struct AdamArgs {
   float step_size[MAXT];           // lr / (1 - beta1^t)
   int n;
   unsigned aligned;                // bit k: all four pointers of tensor k are 16-B aligned
-  float beta1, beta2, eps, inv_bc2_sqrt;  // 1 / sqrt(1 - beta2^t)
+  float beta1, beta2, omb1, omb2, eps, inv_bc2_sqrt;  // 1 - beta (rounded from double, as torch does), 1/sqrt(1 - beta2^t)
   int zero_grads;
 };
 
 __device__ __forceinline__ void adam1(float& p, float& g, float& m, float& v, const AdamArgs& a, int t) {
   // torch::optim::Adam::step: exp_avg = exp_avg*b1 + g*(1-b1); exp_avg_sq = exp_avg_sq*b2 + g*g*(1-b2);
   // denom = sqrt(exp_avg_sq)/sqrt(bias_correction2) + eps; p -= step_size * exp_avg / denom
-  m = m * a.beta1 + g * (1.0f - a.beta1);
-  v = v * a.beta2 + g * g * (1.0f - a.beta2);
+  m = m * a.beta1 + g * a.omb1;
+  v = v * a.beta2 + g * g * a.omb2;
   const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
   p -= a.step_size[t] * (m / denom);
   if (a.zero_grads) g = 0.0f;
@@ -155,14 +155,16 @@ hipError_t launch_activate_backward(int P, int M, const float* rotation_raw, con
 }
 
 hipError_t launch_adam(int n, float* const* params, float* const* grads, float* const* exp_avg,
-                       float* const* exp_avg_sq, const size_t* numel, const float* lr, float beta1, float beta2,
-                       float eps, int step, int zero_grads, hipStream_t s) {
+                       float* const* exp_avg_sq, const size_t* numel, const float* lr, double beta1, double beta2,
+                       double eps, int step, int zero_grads, hipStream_t s) {
   AdamArgs a;
   a.n = n;
-  a.beta1 = beta1;
-  a.beta2 = beta2;
-  a.eps = eps;
-  const double bc1 = 1.0 - pow((double)beta1, (double)step), bc2 = 1.0 - pow((double)beta2, (double)step);
+  a.beta1 = (float)beta1;
+  a.beta2 = (float)beta2;
+  a.omb1 = (float)(1.0 - beta1);  // the options are doubles in torch::optim: 1 - 0.999 = 0.001, not 1 - 0.999f
+  a.omb2 = (float)(1.0 - beta2);
+  a.eps = (float)eps;
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
   a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
   a.zero_grads = zero_grads;
   a.aligned = 0;

@@ -139,6 +139,7 @@ uint32_t gsr_higher_msb(uint32_t n);
  * gsr_adam_step is torch::optim::Adam::step (as configured in src/gs/gaussian.cu:396-428: per-group lr,
  * no weight decay, no amsgrad) for up to 8 tensors in ONE launch; `step` counts from 1; zero_grads != 0
  * clears the gradients it consumed (the reference's zero_grad, src/liw/lioOptimization.cpp:1831-1832).
+ * beta1 / beta2 / eps are doubles as in torch::optim::AdamOptions: 1 - beta is formed in double and then narrowed.
  * Pointer arrays are HOST arrays of device pointers. */
 int gsr_activate(int P, int M, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
                  const float* features_dc, const float* features_rest, float* scales, float* rotations,
@@ -148,7 +149,7 @@ int gsr_activate_backward(int P, int M, const float* rotation_raw, const float* 
                           const float* dL_dshs, float* dL_dscaling_raw, float* dL_drotation_raw,
                           float* dL_dopacity_raw, float* dL_dfeatures_dc, float* dL_dfeatures_rest, void* stream);
 int gsr_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
-                  float* const* exp_avg_sq, const size_t* numel, const float* lr, float beta1, float beta2, float eps,
+                  float* const* exp_avg_sq, const size_t* numel, const float* lr, double beta1, double beta2, double eps,
                   int step, int zero_grads, void* stream);
 
 /* ---- "next" row: the photometric loss that follows every render, fused ----

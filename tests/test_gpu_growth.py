@@ -100,7 +100,7 @@ def test_growth_keeps_parameters_and_adam_state_like_the_references_cat(gpu_devi
                 m, v = mine.moments(k)
                 # f32 rounding of m*b1 + g*(1-b1) near cancellation: absolute slack of a few 1e-8 on values of O(0.1)
                 torch.testing.assert_close(m, ref_m[k], rtol=1e-5, atol=2e-7)
-                torch.testing.assert_close(v, ref_v[k], rtol=1e-5, atol=1e-9)
+                torch.testing.assert_close(v, ref_v[k], rtol=1e-5, atol=1e-8)
     assert mine.P == 3500 and mine.capacity >= 3500
 
 

@@ -49,7 +49,7 @@ ref_v = {k: torch.zeros_like(v) for k, v in ref_p.items()}
 def grow_ref():
     scale_p = covs.diagonal(0, -2, -1)
     new = dict(_xyz=xyz, _scaling=torch.log(torch.sqrt(scale_p * 1.0)),
-               _rotation=torch.zeros((n, 4), device=dev).index_put_((slice(None), torch.tensor(0, device=dev)), torch.tensor(1.0, device=dev)),
+               _rotation=torch.nn.functional.pad(torch.ones((n, 1), device=dev), (0, 3)),
                _opacity=torch.zeros((n, 1), device=dev),
                _features_dc=((rgbs / 255.0 - 0.5) / 0.28209479177387814).unsqueeze(1),
                _features_rest=torch.zeros((n, M - 1, 3), device=dev))
