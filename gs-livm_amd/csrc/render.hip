@@ -274,7 +274,6 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   const float ddelx_dx = 0.5f * (float)fp.W, ddely_dy = 0.5f * (float)fp.H;
   float T = T_final;
   float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, aacc = 0.f;  // accum_rec, accum_acc_rec
-  float last_alpha = 0.f, lc0 = 0.f, lc1 = 0.f, lc2 = 0.f, last_acc = 0.f;
   // entries at or beyond the quad's own last contributor cannot receive gradient from this wave
   const int quad_last = (int)(w == 0 ? ql0 : w == 1 ? ql1 : w == 2 ? ql2 : ql3);
 
@@ -331,24 +330,24 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         if (__ballot(ok) != 0ull) {
           // Branch-free per lane: a lane that does not take this splat runs the same code with alpha = 0 and
           // G = 0.  Every gradient term carries a factor alpha or G, so its partials are exact zeros, and the
-          // recurrence state it leaves behind, (accum' = n, last_alpha' = 0, last_color' = c), reproduces
-          // n' = 0*c + 1*n = n bit for bit at the next visit -- identical to not having visited, without the
-          // save/restore traffic a divergent `if (ok)` costs (T * rcp(1 - 0) = T exactly).
+          // recurrence state is left untouched bit for bit (accum' = 0*c + 1*accum = accum, T * rcp(1 - 0) = T)
+          // -- identical to not having visited, without the save/restore traffic a divergent `if (ok)` costs.
           const float alpha = ok ? araw : 0.0f;
           const float G = ok ? Graw : 0.0f;
-          const float rom = __builtin_amdgcn_rcpf(1.0f - alpha);
+          const float oma = 1.0f - alpha;
+          const float rom = __builtin_amdgcn_rcpf(oma);
           T = T * rom;  // T / (1 - alpha)
           const float dch = alpha * T;
-          const float oml = 1.f - last_alpha;
-          ar0 = last_alpha * lc0 + oml * ar0;
-          ar1 = last_alpha * lc1 + oml * ar1;
-          ar2 = last_alpha * lc2 + oml * ar2;
-          aacc = last_alpha * last_acc + oml * aacc;
           float dL_dalpha = (b.z - ar0) * dp0 + (b.w - ar1) * dp1 + (blue - ar2) * dp2 + (1.0f - aacc) * dacc;
           dL_dalpha *= T;
           dL_dalpha += (-T_final * rom) * bg_dot;
-          lc0 = b.z; lc1 = b.w; lc2 = blue; last_acc = 1.0f;
-          last_alpha = alpha;
+          // Fold this splat into the "everything behind the next one" accumulators NOW: the reference does the
+          // same update at the top of its next iteration from saved (last_alpha, last_color) (backward.cu:533-543);
+          // same operands, same expression, five fewer live registers and no state copies at the loop join.
+          ar0 = __builtin_fmaf(oma, ar0, alpha * b.z);
+          ar1 = __builtin_fmaf(oma, ar1, alpha * b.w);
+          ar2 = __builtin_fmaf(oma, ar2, alpha * blue);
+          aacc = __builtin_fmaf(oma, aacc, alpha);
           // Factors common to every pixel of the splat (opacity, -0.5, 0.5*W, 0.5*H) are applied once per
           // instance when the four quads are combined, not per pixel.
           const float gdx = G * dx, gdy = G * dy;
