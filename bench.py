@@ -285,6 +285,18 @@ def main():
     roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
                     algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_ms=round(kernels[dom]["avg_launch_ms"], 4))
+    # Context for a kernel that is not HBM-bound (the blend kernels): its VALU issue floor from the committed SQ
+    # counter summary (tools/sq_summary.py): wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz).
+    try:
+        with open(os.path.join(ROOT, "profiles", "sq_counters_latest.json")) as fh:
+            sq = json.load(fh)
+        ent = next((v for k, v in sq.items() if k.split("<")[0] == dom and isinstance(v, dict)), None)
+        if ent and ent.get("valu_issue_ms"):
+            roofline["valu_issue"] = dict(wave_instructions_per_launch=ent["SQ_INSTS_VALU"],
+                                          floor_ms=ent["valu_issue_ms"],
+                                          frac_of_launch=round(ent["valu_issue_ms"] / kernels[dom]["avg_launch_ms"], 3))
+    except (OSError, ValueError):
+        pass
     # whole path: sum over kernels of (algorithmic bytes per launch x launches per step)
     b_path = sum(alg.get(k, 0) * d["launches_per_step"] for k, d in kernels.items())
     raster_ms = sum(k["ms_per_step"] for k in kernels.values())

@@ -196,8 +196,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   static thread_local unsigned long long* mailbox = nullptr;  // host pointer
   static thread_local unsigned long long* mailbox_dev = nullptr;
   static thread_local unsigned long long* done_counter = nullptr;  // device: (workgroups done << 40 | sum)
+  static thread_local int mailbox_device = -1;                     // the device the two device pointers belong to
   static thread_local uint32_t ticket = 0;
-  if (!mailbox) {
+  int cur_device = 0;
+  HIP_TRY(hipGetDevice(&cur_device));
+  if (!mailbox || cur_device != mailbox_device) {  // first call of this thread, or the thread switched GPUs
     void* h = nullptr;
     void* d = nullptr;
     void* c = nullptr;
@@ -205,9 +208,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
         hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipMalloc(&c, 64) != hipSuccess ||
         hipMemset(c, 0, 64) != hipSuccess)
       return fail(GSR_ERR_HIP, "cannot allocate the host-mapped mailbox: %s", hipGetErrorString(hipGetLastError()));
-    mailbox = static_cast<unsigned long long*>(h);
+    mailbox = static_cast<unsigned long long*>(h);  // (a previous device's 128 bytes stay allocated: switching is rare)
     mailbox_dev = static_cast<unsigned long long*>(d);
     done_counter = static_cast<unsigned long long*>(c);
+    mailbox_device = cur_device;
+    ticket = 0;
     *mailbox = 0;
     (void)hipDeviceSynchronize();  // the counter is zero before any stream uses it
   }
