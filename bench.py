@@ -67,6 +67,8 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
         "k_activate": P * 4 * (11 + 3 * M) * 2 - P * 24,          # xyz is not touched
         "k_activate_backward": P * 4 * (8 + 3 * M) * 2 + P * 4 * 8,
         "k_adam": P * 4 * (11 + 3 * M) * 7,                       # p, g, m, v read; p, m, v (+ zeroed g) written
+        # one-kernel tail: p, m, v, g (activated space) read; p, m, v + the activated values written
+        "k_model_step": P * 4 * (11 + 3 * M) * 7 + P * 4 * (8 + 3 * M),
         "k_loss_forward": W * H * 3 * 4 * 5, "k_loss_backward": W * H * 3 * 4 * 6, "k_loss_finalize": 0,
     }
 
@@ -80,6 +82,9 @@ def main():
     ap.add_argument("--sh-degree", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-adam", action="store_true", help="time rasterizer fwd+bwd only (diagnostic)")
+    ap.add_argument("--no-fused-tail", action="store_true",
+                    help="activations backward, Adam and next activations as three fused kernels instead of one "
+                         "(gsr_model_step); the one-kernel tail is used whenever gradients are not exchanged")
     ap.add_argument("--torch-optimizer", action="store_true",
                     help="activations / Adam as separate Torch ops (what the reference does) instead of the fused kernels")
     ap.add_argument("--forward-only", action="store_true", help="BASELINE C2 style: colour+depth+silhouette forward only")
@@ -181,6 +186,8 @@ def main():
         return model.activated()
 
     owner_mode = joint and args.sync_mode == "owner"
+    tail = not (joint or args.torch_optimizer or args.no_adam or args.no_fused_tail or args.forward_only)
+    model.fused_tail = tail
 
     def step():
         if owner_mode:
@@ -200,7 +207,9 @@ def main():
             torch.autograd.backward([color, acc], [wc, wa])
         if joint:
             MV.reduce_gradients(grads, dst=0, all_ranks=not owner_mode)
-        if not args.no_adam and (rank == 0 or not owner_mode):
+        if tail:
+            opt.step_model(model)
+        elif not args.no_adam and (rank == 0 or not owner_mode):
             if args.torch_optimizer:
                 opt.step()
             else:
@@ -315,7 +324,9 @@ def main():
                    "views_per_step": n_gpus, "parallelism": "view-parallel x%d" % n_gpus,
                    "sync_mode": args.sync_mode if n_gpus > 1 else None,
                    "adam_in_step": not (args.no_adam or args.forward_only),
-                   "optimizer": "torch ops" if args.torch_optimizer else "fused activations + fused Adam (HIP)",
+                   "optimizer": "torch ops" if args.torch_optimizer else
+                                ("one-kernel tail: activation chain rule + Adam + next activations (HIP)" if tail else
+                                 "fused activations + fused Adam (HIP)"),
                    "loss": args.loss, "host": args.host},
         "fps": round(1e3 / ms_per_step * n_gpus, 2),
         "roofline": roofline,

@@ -36,7 +36,7 @@ EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_byte
            "gsr_higher_msb", "gsr_last_error", "gsr_abi_version", "gsr_kernel_count", "gsr_kernel_name",
            "gsr_profile_enable", "gsr_profile_enable_only", "gsr_profile_read", "gsr_activate", "gsr_activate_backward", "gsr_adam_step",
            "gsr_photometric_loss", "gsr_photometric_loss_workspace", "gsr_init_gaussians", "gsr_ply_row_floats",
-           "gsr_pack_ply_rows")
+           "gsr_pack_ply_rows", "gsr_model_step")
 
 
 def lib():
@@ -91,6 +91,9 @@ def lib():
     L.gsr_ply_row_floats.argtypes = [ci]
     L.gsr_pack_ply_rows.restype = ci
     L.gsr_pack_ply_rows.argtypes = [ci, ci] + [vp] * 7 + [vp]
+    L.gsr_model_step.restype = ci
+    L.gsr_model_step.argtypes = [ci, ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp)] + [vp] * 9 + \
+        [C.POINTER(cf), C.c_double, C.c_double, C.c_double, ci, vp]
     L.gsr_adam_step.restype = ci
     L.gsr_adam_step.argtypes = [ci, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(sz),
                                 C.POINTER(cf), C.c_double, C.c_double, C.c_double, ci, ci, vp]
@@ -354,3 +357,28 @@ def pack_ply_rows(xyz, features_dc, features_rest, opacity, scaling, rotation):
     args = [t.contiguous() for t in (xyz, features_dc, features_rest, opacity, scaling, rotation)]
     _check(lib().gsr_pack_ply_rows(P, M, *[_ptr(t) for t in args], _ptr(rows), _stream()))
     return rows
+
+
+def model_step(params6, exp_avg6, exp_avg_sq6, g_xyz, g_scales, g_rot, g_opac, g_shs, lrs6, beta1, beta2, eps, step,
+               want_activated=True):
+    """Chain rule of the activations + Adam on the six groups + activations of the updated parameters, one launch
+    (include/gsraster.h, gsr_model_step).  params6 in the order xyz, features_dc, features_rest, scaling, rotation,
+    opacity.  Returns (scales, rotations, opacities [P,1], shs) of the UPDATED model, or None."""
+    xyz, fdc, frest = params6[0], params6[1], params6[2]
+    P = int(xyz.size(0))
+    M = 1 + (int(frest.size(1)) if frest.numel() else 0)
+    for t in list(params6) + list(exp_avg6) + list(exp_avg_sq6) + [g_xyz, g_scales, g_rot, g_opac, g_shs]:
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float32
+    outs = None
+    if want_activated:
+        f32 = dict(dtype=torch.float32, device=xyz.device)
+        outs = (torch.empty((P, 3), **f32), torch.empty((P, 4), **f32), torch.empty((P, 1), **f32),
+                torch.empty((P, M, 3), **f32))
+    VP = C.c_void_p * 6
+    arr = lambda ts: VP(*[t.data_ptr() if t.numel() else None for t in ts])  # noqa: E731
+    lr = (C.c_float * 6)(*[float(x) for x in lrs6])
+    o = outs if outs is not None else (None, None, None, None)
+    _check(lib().gsr_model_step(P, M, arr(params6), arr(exp_avg6), arr(exp_avg_sq6), _ptr(g_xyz), _ptr(g_scales),
+                                _ptr(g_rot), _ptr(g_opac), _ptr(g_shs), _ptr(o[0]), _ptr(o[1]), _ptr(o[2]), _ptr(o[3]), lr,
+                                float(beta1), float(beta2), float(eps), int(step), _stream()))
+    return outs

@@ -63,7 +63,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top", "k_sort_scatter", "k_tile_ranges", "k_blend_forward",
     "k_blend_backward", "k_compact_touched", "k_gather_records", "k_gaussian_backward", "k_mark_visible", "k_sort_hist[depth]",
     "k_sort_scan_chunks[depth]", "k_sort_scan_top[depth]", "k_sort_scatter[depth]", "k_activate",
-    "k_activate_backward", "k_adam", "k_loss_forward", "k_loss_finalize", "k_loss_backward", "k_init_gaussians", "k_pack_ply_rows"};
+    "k_activate_backward", "k_adam", "k_loss_forward", "k_loss_finalize", "k_loss_backward", "k_init_gaussians", "k_pack_ply_rows", "k_model_step"};
 
 extern "C" {
 
@@ -387,6 +387,26 @@ int gsr_photometric_loss(int channels, int height, int width, const float* img, 
                 loss_workspace_bytes(channels, height, width));
   HIP_TRY(launch_photometric_loss(channels, height, width, img, gt, window11_host, lambda_dssim, loss_out3, dL_dimg,
                                   workspace, (hipStream_t)stream_));
+  return GSR_OK;
+}
+
+int gsr_model_step(int P, int M, float* const* params6, float* const* exp_avg6, float* const* exp_avg_sq6,
+                   const float* dL_dxyz, const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
+                   const float* dL_dshs, float* scales_out, float* rotations_out, float* opacities_out, float* shs_out,
+                   const float* lr6, double beta1, double beta2, double eps, int step, void* stream_) {
+  g_err[0] = 0;
+  if (P < 0 || M < 1 || M > 16) return fail(GSR_ERR_INVALID_ARGUMENT, "bad P/M");
+  if (step < 1) return fail(GSR_ERR_INVALID_ARGUMENT, "step counts from 1");
+  if (P == 0) return GSR_OK;
+  if (!params6 || !exp_avg6 || !exp_avg_sq6 || !lr6 || !dL_dxyz || !dL_dscales || !dL_drotations || !dL_dopacities ||
+      !dL_dshs)
+    return fail(GSR_ERR_INVALID_ARGUMENT, "null pointer");
+  for (int k = 0; k < 6; k++)
+    if ((k != 2 || M > 1) && (!params6[k] || !exp_avg6[k] || !exp_avg_sq6[k]))
+      return fail(GSR_ERR_INVALID_ARGUMENT, "null tensor pointer (group %d)", k);
+  HIP_TRY(launch_model_step(P, M, params6, exp_avg6, exp_avg_sq6, dL_dxyz, dL_dscales, dL_drotations, dL_dopacities,
+                            dL_dshs, scales_out, rotations_out, opacities_out, shs_out, lr6, beta1, beta2, eps, step,
+                            (hipStream_t)stream_));
   return GSR_OK;
 }
 

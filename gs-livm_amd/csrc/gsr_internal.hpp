@@ -246,6 +246,10 @@ hipError_t launch_init_gaussians(int n, int M, const float* xyz, const float* co
 hipError_t launch_pack_ply_rows(int P, int M, const float* xyz, const float* fdc, const float* frest,
                                 const float* opacity, const float* scaling, const float* rotation, float* rows,
                                 hipStream_t s);
+hipError_t launch_model_step(int P, int M, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                             const float* g_xyz, const float* g_scales, const float* g_rot, const float* g_opac,
+                             const float* g_shs, float* a_scales, float* a_rot, float* a_opac, float* a_shs,
+                             const float* lr, double beta1, double beta2, double eps, int step, hipStream_t s);
 hipError_t launch_adam(int n, float* const* params, float* const* grads, float* const* exp_avg,
                        float* const* exp_avg_sq, const size_t* numel, const float* lr, double beta1, double beta2,
                        double eps, int step, int zero_grads, hipStream_t s);
@@ -259,7 +263,7 @@ enum KernelId {
   K_PREPROCESS = 0, K_POINT_OFFSETS, K_SCAN_OFFSETS, K_EMIT, K_SORT_HIST,
   K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_COMPACT_TOUCHED,
   K_GATHER_RECORDS, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_DSORT_HIST, K_DSORT_SCAN_CHUNKS, K_DSORT_SCAN_TOP,
-  K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_LOSS_FWD, K_LOSS_FINALIZE, K_LOSS_BWD, K_INIT_GAUSSIANS, K_PACK_PLY, K_COUNT
+  K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_LOSS_FWD, K_LOSS_FINALIZE, K_LOSS_BWD, K_INIT_GAUSSIANS, K_PACK_PLY, K_MODEL_STEP, K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);

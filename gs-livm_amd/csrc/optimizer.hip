@@ -133,6 +133,180 @@ __global__ __launch_bounds__(256) void k_adam(const AdamArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_model_step: the whole optimiser tail of one iteration in ONE pass over the model --
+//   chain rule of the activations (= k_activate_backward) -> Adam on all six groups (= k_adam) ->
+//   the activated values of the UPDATED parameters for the next forward (= k_activate),
+// one thread per Gaussian.  Same arithmetic as the three separate kernels (the activated scales / opacity the
+// chain rule needs are recomputed from the raw parameters: bit-identical to what the forward used), but the
+// raw-space gradients never exist in memory and the parameters are read once: 436 instead of 608 bytes per
+// Gaussian at M = 1, one launch instead of three.
+// ------------------------------------------------------------------------------------------------
+struct StepArgs {
+  int P, M;
+  float *xyz, *fdc, *frest, *scaling, *rot, *opac;  // raw parameters, updated in place
+  float* m[6];                                      // exp_avg    in group order xyz, f_dc, f_rest, scaling, rotation, opacity
+  float* v[6];                                      // exp_avg_sq
+  const float *g_xyz, *g_scales, *g_rot, *g_opac, *g_shs;  // dL/d(xyz, activated scales / rotations / opacities / shs)
+  float *a_scales, *a_rot, *a_opac, *a_shs;         // activated values of the updated parameters (may be null)
+  float step_size[6];
+  float beta1, beta2, omb1, omb2, eps, inv_bc2_sqrt;
+  unsigned long long end[6];    // cumulative count of 4-element groups, ceil(numel/4) per tensor
+  unsigned long long numel[6];
+  unsigned aligned;             // bit k: every pointer the 16-byte path of tensor k touches is 16-B aligned
+};
+
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const StepArgs& a, int grp) {
+  m = m * a.beta1 + g * a.omb1;
+  v = v * a.beta2 + g * g * a.omb2;
+  const float denom = sqrtf(v) * a.inv_bc2_sqrt + a.eps;
+  return p - a.step_size[grp] * (m / denom);
+}
+
+// Work decomposition as in k_adam: thread #idx owns 4 consecutive floats of the virtual concatenation of the six
+// parameter tensors (each rounded up to a multiple of 4), so every access is a coalesced 16-byte one; the
+// activation kind of the tensor decides how the gradient is pulled back and what is written for the next forward:
+//   xyz: identity | f_dc, f_rest: identity, gradient / value live inside shs [P][M][3] | scaling: exp |
+//   rotation: normalise (one thread = one quaternion) | opacity: sigmoid.
+// The 16-byte path needs 16-byte-aligned tensors (StepArgs::aligned) and, for the two SH tensors, M == 1 (then
+// shs and f_dc coincide); otherwise the thread handles its 4 elements one by one.
+__device__ __forceinline__ void step_elem(const StepArgs& a, int t, unsigned long long e) {
+  const int M = a.M, R1 = 3 * (M - 1);
+  float* P_[6] = {a.xyz, a.fdc, a.frest, a.scaling, a.rot, a.opac};
+  float p = P_[t][e], m = a.m[t][e], v = a.v[t][e], g;
+  if (t == 0) g = a.g_xyz[e];
+  else if (t == 1) g = a.g_shs[(e / 3) * (unsigned long long)(3 * M) + e % 3];
+  else if (t == 2) g = a.g_shs[(e / R1) * (unsigned long long)(3 * M) + 3 + e % R1];
+  else if (t == 3) g = a.g_scales[e] * expf(p);
+  else { const float sg = sigmoidf_(p); g = a.g_opac[e] * sg * (1.0f - sg); }
+  p = adam_update(p, g, m, v, a, t);
+  P_[t][e] = p; a.m[t][e] = m; a.v[t][e] = v;
+  if (t == 1 && a.a_shs) a.a_shs[(e / 3) * (unsigned long long)(3 * M) + e % 3] = p;
+  if (t == 2 && a.a_shs) a.a_shs[(e / R1) * (unsigned long long)(3 * M) + 3 + e % R1] = p;
+  if (t == 3 && a.a_scales) a.a_scales[e] = expf(p);
+  if (t == 5 && a.a_opac) a.a_opac[e] = sigmoidf_(p);
+}
+
+__global__ __launch_bounds__(256) void k_model_step(const StepArgs a) {
+  const unsigned long long idx = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+  int t = 0;
+  unsigned long long start = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) {
+    if (idx >= a.end[k]) { t = k + 1; start = a.end[k]; }
+  }
+  if (t >= 6) return;
+  const unsigned long long e0 = (idx - start) * 4;
+  const unsigned long long left = a.numel[t] - e0;
+  float* P_[6] = {a.xyz, a.fdc, a.frest, a.scaling, a.rot, a.opac};
+  if (t == 4) {  // one quaternion (numel is a multiple of 4)
+    const bool al = (a.aligned >> 4) & 1u;  // wave-uniform
+    const float4 q = al ? *reinterpret_cast<const float4*>(a.rot + e0)
+                        : make_float4(a.rot[e0], a.rot[e0 + 1], a.rot[e0 + 2], a.rot[e0 + 3]);
+    const float4 g = al ? *reinterpret_cast<const float4*>(a.g_rot + e0)
+                        : make_float4(a.g_rot[e0], a.g_rot[e0 + 1], a.g_rot[e0 + 2], a.g_rot[e0 + 3]);
+    const float4 m4 = al ? *reinterpret_cast<const float4*>(a.m[4] + e0)
+                         : make_float4(a.m[4][e0], a.m[4][e0 + 1], a.m[4][e0 + 2], a.m[4][e0 + 3]);
+    const float4 v4 = al ? *reinterpret_cast<const float4*>(a.v[4] + e0)
+                         : make_float4(a.v[4][e0], a.v[4][e0 + 1], a.v[4][e0 + 2], a.v[4][e0 + 3]);
+    const float nrm = sqrtf(q.x * q.x + q.y * q.y + q.z * q.z + q.w * q.w);
+    float go[4];
+    if (nrm > 1e-12f) {  // y = x/|x|:  dx = (g - y (y.g)) / |x|   (as k_activate_backward)
+      const float inv = 1.0f / nrm;
+      const float yx = q.x * inv, yy = q.y * inv, yz = q.z * inv, yw = q.w * inv;
+      const float d = yx * g.x + yy * g.y + yz * g.z + yw * g.w;
+      go[0] = (g.x - yx * d) * inv; go[1] = (g.y - yy * d) * inv; go[2] = (g.z - yz * d) * inv; go[3] = (g.w - yw * d) * inv;
+    } else {
+      go[0] = g.x * 1e12f; go[1] = g.y * 1e12f; go[2] = g.z * 1e12f; go[3] = g.w * 1e12f;
+    }
+    const float qo[4] = {q.x, q.y, q.z, q.w};
+    float mo[4] = {m4.x, m4.y, m4.z, m4.w}, vo[4] = {v4.x, v4.y, v4.z, v4.w}, pn[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) pn[k] = adam_update(qo[k], go[k], mo[k], vo[k], a, 4);
+    const float inv2 = 1.0f / fmaxf(sqrtf(pn[0] * pn[0] + pn[1] * pn[1] + pn[2] * pn[2] + pn[3] * pn[3]), 1e-12f);
+    if (al) {
+      *reinterpret_cast<float4*>(a.rot + e0) = make_float4(pn[0], pn[1], pn[2], pn[3]);
+      *reinterpret_cast<float4*>(a.m[4] + e0) = make_float4(mo[0], mo[1], mo[2], mo[3]);
+      *reinterpret_cast<float4*>(a.v[4] + e0) = make_float4(vo[0], vo[1], vo[2], vo[3]);
+      if (a.a_rot)
+        *reinterpret_cast<float4*>(a.a_rot + e0) = make_float4(pn[0] * inv2, pn[1] * inv2, pn[2] * inv2, pn[3] * inv2);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        a.rot[e0 + k] = pn[k]; a.m[4][e0 + k] = mo[k]; a.v[4][e0 + k] = vo[k];
+        if (a.a_rot) a.a_rot[e0 + k] = pn[k] * inv2;
+      }
+    }
+    return;
+  }
+  const bool sh_direct = a.M == 1;  // shs == f_dc in memory
+  if (left >= 4 && ((a.aligned >> t) & 1u) && (t == 0 || t == 3 || t == 5 || (t == 1 && sh_direct))) {
+    float4 p = *reinterpret_cast<float4*>(P_[t] + e0);
+    float4 m = *reinterpret_cast<float4*>(a.m[t] + e0);
+    float4 v = *reinterpret_cast<float4*>(a.v[t] + e0);
+    const float* gsrc = t == 0 ? a.g_xyz : t == 1 ? a.g_shs : t == 3 ? a.g_scales : a.g_opac;
+    float4 g = *reinterpret_cast<const float4*>(gsrc + e0);
+    if (t == 3) { g.x *= expf(p.x); g.y *= expf(p.y); g.z *= expf(p.z); g.w *= expf(p.w); }
+    if (t == 5) {
+      const float s0 = sigmoidf_(p.x), s1 = sigmoidf_(p.y), s2 = sigmoidf_(p.z), s3 = sigmoidf_(p.w);
+      g.x *= s0 * (1.0f - s0); g.y *= s1 * (1.0f - s1); g.z *= s2 * (1.0f - s2); g.w *= s3 * (1.0f - s3);
+    }
+    p.x = adam_update(p.x, g.x, m.x, v.x, a, t);
+    p.y = adam_update(p.y, g.y, m.y, v.y, a, t);
+    p.z = adam_update(p.z, g.z, m.z, v.z, a, t);
+    p.w = adam_update(p.w, g.w, m.w, v.w, a, t);
+    *reinterpret_cast<float4*>(P_[t] + e0) = p;
+    *reinterpret_cast<float4*>(a.m[t] + e0) = m;
+    *reinterpret_cast<float4*>(a.v[t] + e0) = v;
+    if (t == 1 && a.a_shs) *reinterpret_cast<float4*>(a.a_shs + e0) = p;
+    if (t == 3 && a.a_scales)
+      *reinterpret_cast<float4*>(a.a_scales + e0) = make_float4(expf(p.x), expf(p.y), expf(p.z), expf(p.w));
+    if (t == 5 && a.a_opac)
+      *reinterpret_cast<float4*>(a.a_opac + e0) = make_float4(sigmoidf_(p.x), sigmoidf_(p.y), sigmoidf_(p.z), sigmoidf_(p.w));
+  } else {
+    const int cnt = left < 4 ? (int)left : 4;
+    for (int k = 0; k < cnt; k++) step_elem(a, t, e0 + k);
+  }
+}
+
+hipError_t launch_model_step(int P, int M, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
+                             const float* g_xyz, const float* g_scales, const float* g_rot, const float* g_opac,
+                             const float* g_shs, float* a_scales, float* a_rot, float* a_opac, float* a_shs,
+                             const float* lr, double beta1, double beta2, double eps, int step, hipStream_t s) {
+  StepArgs a;
+  a.P = P; a.M = M;
+  a.xyz = params[0]; a.fdc = params[1]; a.frest = params[2]; a.scaling = params[3]; a.rot = params[4]; a.opac = params[5];
+  const double bc1 = 1.0 - pow(beta1, (double)step), bc2 = 1.0 - pow(beta2, (double)step);
+  for (int k = 0; k < 6; k++) {
+    a.m[k] = exp_avg[k];
+    a.v[k] = exp_avg_sq[k];
+    a.step_size[k] = (float)((double)lr[k] / bc1);
+  }
+  a.g_xyz = g_xyz; a.g_scales = g_scales; a.g_rot = g_rot; a.g_opac = g_opac; a.g_shs = g_shs;
+  a.a_scales = a_scales; a.a_rot = a_rot; a.a_opac = a_opac; a.a_shs = a_shs;
+  a.beta1 = (float)beta1; a.beta2 = (float)beta2;
+  a.omb1 = (float)(1.0 - beta1); a.omb2 = (float)(1.0 - beta2);
+  a.eps = (float)eps;
+  a.inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  const unsigned long long P64 = (unsigned long long)P;
+  const unsigned long long ne[6] = {3 * P64, 3 * P64, 3 * (unsigned long long)(M - 1) * P64, 3 * P64, 4 * P64, P64};
+  const void* extra[6][2] = {{g_xyz, nullptr}, {g_shs, a_shs}, {nullptr, nullptr}, {g_scales, a_scales},
+                             {g_rot, a_rot}, {g_opac, a_opac}};
+  unsigned long long cum = 0;
+  a.aligned = 0;
+  for (int k = 0; k < 6; k++) {
+    a.numel[k] = ne[k];
+    cum += (ne[k] + 3) / 4;
+    a.end[k] = cum;
+    const uintptr_t bits = (uintptr_t)params[k] | (uintptr_t)exp_avg[k] | (uintptr_t)exp_avg_sq[k] |
+                           (uintptr_t)extra[k][0] | (uintptr_t)extra[k][1];
+    if ((bits & 15u) == 0) a.aligned |= 1u << k;
+  }
+  ProfScope ps(K_MODEL_STEP, s);
+  hipLaunchKernelGGL(k_model_step, dim3((unsigned)((cum + 255) / 256)), dim3(256), 0, s, a);
+  return hipGetLastError();
+}
+
 hipError_t launch_activate(int P, int M, const float* scaling_raw, const float* rotation_raw, const float* opacity_raw,
                            const float* f_dc, const float* f_rest, float* scales, float* rotations, float* opacities,
                            float* shs, hipStream_t s) {

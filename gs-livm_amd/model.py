@@ -37,6 +37,36 @@ class FusedActivations(torch.autograd.Function):
                                        g_shs.contiguous())
 
 
+class _StashingActivations(torch.autograd.Function):
+    """FusedActivations for the fused optimiser tail (FusedAdam.step_model): forward hands out the activated
+    values the last step already computed (no launch) or computes them; backward does NOT run the chain rule -- it
+    parks the gradients w.r.t. the activated tensors on the model, and FusedAdam.step_model applies chain rule +
+    Adam + next activations in one kernel (csrc/optimizer.hip, k_model_step)."""
+
+    @staticmethod
+    def forward(ctx, model, scaling_raw, rotation_raw, opacity_raw, features_dc, features_rest):
+        ctx.model = model
+        cached = model._next_act
+        model._next_act = None
+        if cached is not None:
+            return cached
+        return _capi.activate(scaling_raw.contiguous(), rotation_raw.contiguous(), opacity_raw.contiguous(),
+                              features_dc.contiguous(), features_rest.contiguous())
+
+    @staticmethod
+    def backward(ctx, g_scales, g_rot, g_opac, g_shs):
+        m = ctx.model
+        new = [g_scales, g_rot, g_opac, g_shs]
+        shapes = [(m._scaling.shape), (m._rotation.shape), (m._opacity.shape),
+                  (m._xyz.shape[0], 1 + m._features_rest.shape[1], 3)]
+        new = [torch.zeros(sh, device=m._xyz.device) if g is None else g.contiguous() for g, sh in zip(new, shapes)]
+        if m._act_grads is None:
+            m._act_grads = new
+        else:  # several backward passes before one step (views rendered in separate graphs): gradients add up
+            m._act_grads = [a + b for a, b in zip(m._act_grads, new)]
+        return None, None, None, None, None, None
+
+
 class GaussianParameters(torch.nn.Module):
     """The leaf tensors of GaussianModel (include/gs/gs/gaussian.cuh:107-119) and its getters."""
 
@@ -45,11 +75,21 @@ class GaussianParameters(torch.nn.Module):
         P = torch.nn.Parameter
         self._xyz, self._features_dc, self._features_rest = P(xyz), P(features_dc), P(features_rest)
         self._scaling, self._rotation, self._opacity = P(scaling), P(rotation), P(opacity)
+        self._init_fused_tail()
+
+    def _init_fused_tail(self):
+        self.fused_tail = False   # True: activated() parks gradients for FusedAdam.step_model (see there)
+        self._next_act = None     # activated values of the current parameters, left by the last step_model
+        self._act_grads = None    # gradients w.r.t. (scales, rotations, opacities, shs) parked by backward
 
     def activated(self):
         """(xyz, opacity [P,1], scales, rotations, shs) through one fused node."""
-        scales, rot, opac, shs = FusedActivations.apply(self._scaling, self._rotation, self._opacity,
-                                                        self._features_dc, self._features_rest)
+        if self.fused_tail:
+            scales, rot, opac, shs = _StashingActivations.apply(self, self._scaling, self._rotation, self._opacity,
+                                                                self._features_dc, self._features_rest)
+        else:
+            scales, rot, opac, shs = FusedActivations.apply(self._scaling, self._rotation, self._opacity,
+                                                            self._features_dc, self._features_rest)
         return self._xyz, opac, scales, rot, shs
 
     # reference getter names (each call runs the fused node; use activated() to get all at once)
@@ -111,6 +151,35 @@ class FusedAdam(torch.optim.Optimizer):
             _capi.adam_step(ps[i:i + 8], gs[i:i + 8], ms[i:i + 8], vs[i:i + 8], lrs[i:i + 8], betas[0], betas[1],
                             eps, self._step, zero_grads)
 
+    @torch.no_grad()
+    def step_model(self, model):
+        """The optimiser tail of one iteration in ONE launch (k_model_step): chain rule of the activations, Adam on
+        the six groups of `model` (which must be this optimiser's six groups, `model.fused_tail = True`), and the
+        activated values of the updated parameters, which the next `model.activated()` hands out without a launch.
+        Equivalent to FusedActivations' backward + step(); the raw-space gradients are never materialised."""
+        assert model.fused_tail and model._act_grads is not None and model._xyz.grad is not None, \
+            "step_model needs a backward through model.activated() with model.fused_tail = True"
+        ps = [model._xyz, model._features_dc, model._features_rest, model._scaling, model._rotation, model._opacity]
+        lrs, ms, vs = [], [], []
+        betas, eps = self.defaults["betas"], self.defaults["eps"]
+        for p in ps:
+            if p.numel() == 0:  # e.g. features_rest at SH degree 0: nothing to step, its group may be absent
+                lrs.append(0.0); ms.append(p.detach()); vs.append(p.detach())
+                continue
+            grp = next(g for g in self.param_groups if any(q is p for q in g["params"]))
+            st = self.state[p]
+            if not st:
+                st["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                st["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            lrs.append(grp["lr"]); ms.append(st["exp_avg"]); vs.append(st["exp_avg_sq"])
+            betas, eps = grp["betas"], grp["eps"]
+        self._step += 1
+        g_scales, g_rot, g_opac, g_shs = model._act_grads
+        model._next_act = _capi.model_step(ps, ms, vs, model._xyz.grad.contiguous(), g_scales, g_rot, g_opac, g_shs, lrs,
+                                           betas[0], betas[1], eps, self._step)
+        model._act_grads = None
+        model._xyz.grad = None
+
 
 class GrowableGaussians(GaussianParameters):
     """The six leaves and their Adam moments as CAPACITY buffers; the leaves are views of the first P rows.
@@ -128,6 +197,7 @@ class GrowableGaussians(GaussianParameters):
 
     def __init__(self, capacity, M, device):
         torch.nn.Module.__init__(self)
+        self._init_fused_tail()
         self.M, self.P, self.capacity, self.device = int(M), 0, 0, torch.device(device)
         self._buf, self._m, self._v = {}, {}, {}
         self._optimizer = None
@@ -151,6 +221,7 @@ class GrowableGaussians(GaussianParameters):
         """Leaves = views of the first P rows (new Parameter objects, same storage); optimiser state follows."""
         for name in self._NAMES:
             setattr(self, name, torch.nn.Parameter(self._buf[name][:self.P]))
+        self._next_act = None  # the cached activations describe the old row count
         if self._optimizer is not None:
             self._optimizer.rebind(self)
 

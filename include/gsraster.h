@@ -148,6 +148,16 @@ int gsr_activate_backward(int P, int M, const float* rotation_raw, const float* 
                           const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
                           const float* dL_dshs, float* dL_dscaling_raw, float* dL_drotation_raw,
                           float* dL_dopacity_raw, float* dL_dfeatures_dc, float* dL_dfeatures_rest, void* stream);
+/* gsr_model_step: the whole optimiser tail in one pass over the model -- gsr_activate_backward's chain rule, Adam on
+ * the six groups (order xyz, features_dc, features_rest, scaling, rotation, opacity: the reference's group order,
+ * src/gs/gaussian.cu:396-428) and gsr_activate of the UPDATED parameters for the next forward (outputs nullable).
+ * Gradients are w.r.t. xyz and the ACTIVATED scales / rotations / opacities / shs, i.e. exactly what the
+ * rasterizer's backward returns; the raw-space gradients never reach memory.  Same arithmetic as the three
+ * separate entry points. */
+int gsr_model_step(int P, int M, float* const* params6, float* const* exp_avg6, float* const* exp_avg_sq6,
+                   const float* dL_dxyz, const float* dL_dscales, const float* dL_drotations, const float* dL_dopacities,
+                   const float* dL_dshs, float* scales_out, float* rotations_out, float* opacities_out, float* shs_out,
+                   const float* lr6, double beta1, double beta2, double eps, int step, void* stream);
 int gsr_adam_step(int n_tensors, float* const* params, float* const* grads, float* const* exp_avg,
                   float* const* exp_avg_sq, const size_t* numel, const float* lr, double beta1, double beta2, double eps,
                   int step, int zero_grads, void* stream);

@@ -90,9 +90,10 @@ def test_one_optimiser_iteration_fused_vs_torch_ops(gpu_device):
     dcol, dacc = S.make_upstream_grads(W, H, 9)
     wc, wa = torch.from_numpy(dcol).to(dev) * 1e3, torch.from_numpy(dacc).to(dev) * 1e3
 
-    def run(fused):
+    def run(fused, tail=False):
         m = G.GaussianParameters(r["xyz"].clone(), r["f_dc"].clone(), r["f_rest"].clone(), r["scaling"].clone(),
                                  r["rotation"].clone(), r["opacity"].clone())
+        m.fused_tail = tail
         opt = (G.FusedAdam if fused else torch.optim.Adam)(m.param_groups(), eps=1e-15)
         for _ in range(3):
             if fused:
@@ -104,11 +105,25 @@ def test_one_optimiser_iteration_fused_vs_torch_ops(gpu_device):
             means2D = torch.zeros_like(xyz, requires_grad=True)
             color, radii, depth, acc = G.GaussianRasterizer(st)(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
             torch.autograd.backward([color, acc], [wc, wa])
-            opt.step()
+            if tail:
+                assert m._scaling.grad is None and m._act_grads is not None  # raw-space gradients never materialise
+                opt.step_model(m)
+                assert m._next_act is not None and m._act_grads is None
+            else:
+                opt.step()
             if not fused:
                 opt.zero_grad(set_to_none=True)
-        return [p.detach().clone() for p in m.parameters()]
+        out = [p.detach().clone() for p in m.parameters()]
+        if tail:  # the activations the step left behind are those of the updated parameters
+            sc, rot, op, shs = m._next_act
+            torch.testing.assert_close(sc, torch.exp(m._scaling.detach()), rtol=2e-6, atol=1e-7)
+            torch.testing.assert_close(rot, torch.nn.functional.normalize(m._rotation.detach()), rtol=2e-6, atol=1e-7)
+            torch.testing.assert_close(op, torch.sigmoid(m._opacity.detach()), rtol=2e-6, atol=1e-7)
+            torch.testing.assert_close(shs, torch.cat([m._features_dc, m._features_rest], 1).detach(), rtol=0, atol=0)
+        return out
 
-    a, b = run(True), run(False)
+    a, b, c = run(True), run(False), run(True, tail=True)
     for x, y in zip(a, b):
         torch.testing.assert_close(x, y, rtol=1e-4, atol=2e-6)
+    for x, z in zip(a, c):  # one-kernel tail vs three kernels: the same arithmetic
+        torch.testing.assert_close(z, x, rtol=5e-6, atol=1e-7)
