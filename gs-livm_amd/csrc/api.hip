@@ -266,11 +266,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
   const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
   const bool key16 = tiles <= 65536;  // tile ids fit 16 bits for every image up to 4096 x 4096
-  STAGE(launch_scan_offsets(fp, g, R, b.chunk_first, im.ranges, stream));
+  STAGE(launch_scan_offsets(fp, g, R, b.chunk_first, im.ranges, b.tsort.counts, stream));
   STAGE(launch_emit(fp, g, R, b.chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB,
-                    b.inst_flag, key16, stream));
+                    b.inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16, stream));
   STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, R, tile_bits, start_in_A,
-                          /*is_depth_sort=*/false, key16, stream));
+                          /*is_depth_sort=*/false, key16, /*first_hist_done=*/true, stream));
   STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, key16, stream));
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
   return R;

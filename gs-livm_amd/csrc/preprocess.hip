@@ -360,13 +360,16 @@ constexpr unsigned long long SC_GLOBAL = 2ull << 32, SC_LOCAL = 1ull << 32;
 
 __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp, GeomState g, const int R,
                                                             uint32_t* __restrict__ chunk_first,
-                                                            uint2* __restrict__ ranges) {
+                                                            uint2* __restrict__ ranges,
+                                                            uint32_t* __restrict__ counts0, const size_t ncounts0) {
   __shared__ uint32_t wtot[PRE_BLOCK / 64];
   __shared__ uint32_t s_tile, s_prefix;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // side job: (0, 0) for the tiles no instance lands in
   for (int t = blockIdx.x * PRE_BLOCK + tid; t < fp.gx * fp.gy; t += gridDim.x * PRE_BLOCK)
     ranges[t] = make_uint2(0u, 0u);
+  // side job: clear the digit counts of the tile sort's first pass (k_emit accumulates them while emitting)
+  for (size_t q = (size_t)blockIdx.x * PRE_BLOCK + tid; q < ncounts0; q += (size_t)gridDim.x * PRE_BLOCK) counts0[q] = 0u;
   if (tid == 0) s_tile = atomicAdd(g.dsort.tickets() + 4, 1u);  // every lower tile is already running
   __syncthreads();
   const uint32_t tile = s_tile;
@@ -470,9 +473,12 @@ template <typename K>
 __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g, const int R,
                                               const uint32_t* __restrict__ chunk_first,
                                               K* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out,
-                                              uint8_t* __restrict__ inst_flag) {
+                                              uint8_t* __restrict__ inst_flag, uint32_t* __restrict__ counts0,
+                                              const uint32_t digit_mask0) {
   __shared__ uint32_t s_off[EMIT_CHUNK + 2], s_id[EMIT_CHUNK + 1], s_rect[EMIT_CHUNK + 1], s_inv[EMIT_CHUNK + 1];
+  __shared__ uint32_t hist[256];  // digit counts of the tile sort's FIRST pass for this workgroup's 2048 slots
   const int tid = threadIdx.x;
+  hist[tid] = 0;
   const uint32_t c0 = (uint32_t)blockIdx.x * EMIT_CHUNK;
   const uint32_t c1 = c0 + EMIT_CHUNK < (uint32_t)R ? c0 + EMIT_CHUNK : (uint32_t)R;
   // i0 = Gaussian covering slot c0; i1 = last Gaussian whose run starts before c1
@@ -492,7 +498,7 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
   // Each thread owns EIGHT consecutive slots: one bisection for the first, then it walks (row, col) and steps to
   // the next Gaussian when a run ends -- 4x fewer LDS round trips than a search per slot, 32-byte stores.
   const uint32_t t0 = c0 + (uint32_t)tid * 8u;
-  if (t0 >= c1) return;
+  if (t0 < c1) {
   int j = 0;
   {
     int lo = 0, hi = S - 1;  // largest j with s_off[j] <= t0
@@ -542,6 +548,15 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
       inst_flag[t0 + k] = 0;
     }
   }
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (t0 + (uint32_t)k < c1) atomicAdd(&hist[tk[k] & digit_mask0], 1u);
+  }
+  // The sort's first pass needs per-4096-slot digit counts: two emitting workgroups share a sort tile, so each adds
+  // its non-zero bins (k_scan_offsets cleared the array) -- this replaces a histogram pass over all the keys.
+  __syncthreads();
+  const uint32_t hc = hist[tid];
+  if (hc) atomicAdd(&counts0[(size_t)(c0 / SORT_TILE) * 256 + tid], hc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -919,24 +934,26 @@ hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t 
 }
 
 hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint2* ranges,
-                               hipStream_t s) {
+                               uint32_t* counts0, hipStream_t s) {
+  const size_t ncounts0 = (size_t)((R + SORT_TILE - 1) / SORT_TILE) * 256;
   ProfScope ps(K_SCAN_OFFSETS, s);
   hipLaunchKernelGGL(k_scan_offsets, dim3((fp.P + SCAN_TILE - 1) / SCAN_TILE), dim3(PRE_BLOCK), 0, s, fp, g, R,
-                     chunk_first, ranges);
+                     chunk_first, ranges, counts0, ncounts0);
   return hipGetLastError();
 }
 
 hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
-                       uint32_t* ivals_out, uint8_t* inst_flag, bool key16, hipStream_t s) {
+                       uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_mask0, bool key16,
+                       hipStream_t s) {
   if (R <= 0) return hipSuccess;
   ProfScope ps(K_EMIT, s);
   const dim3 grid((R + EMIT_CHUNK - 1) / EMIT_CHUNK);
   if (key16)
     hipLaunchKernelGGL(k_emit<uint16_t>, grid, dim3(256), 0, s, fp, g, R, chunk_first,
-                       reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag);
+                       reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_mask0);
   else
     hipLaunchKernelGGL(k_emit<uint32_t>, grid, dim3(256), 0, s, fp, g, R, chunk_first, tkeys_out, ivals_out,
-                       inst_flag);
+                       inst_flag, counts0, digit_mask0);
   return hipGetLastError();
 }
 

@@ -380,7 +380,8 @@ static bool lds_atomic_rank_ok(hipStream_t s) {
 // picks start_in_A = (passes even) so the result always lands in (keysA, valsA).
 template <typename K>
 static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t* valsB, SortScratch sc, int n,
-                                  int end_bit, bool start_in_A, bool is_depth_sort, hipStream_t s) {
+                                  int end_bit, bool start_in_A, bool is_depth_sort, bool first_hist_done,
+                                  hipStream_t s) {
   const int kb = is_depth_sort ? (int)K_DSORT_HIST - (int)K_SORT_HIST : 0;  // profiler ids of this sort
   const int ntiles = (n + SORT_TILE - 1) / SORT_TILE;
   const int nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
@@ -394,7 +395,7 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
     K* kout = inA ? keysB : keysA;
     uint32_t* vout = inA ? valsB : valsA;
     const int shift = nbits * p;
-    {
+    if (!(p == 0 && first_hist_done)) {  // the emitter already left the first pass's counts in sc.counts
       ProfScope ps(K_SORT_HIST + kb, s);
       hipLaunchKernelGGL(k_sort_hist<K>, dim3(ntiles), dim3(256), 0, s, kin, n, shift, nbits, sc.counts);
     }
@@ -425,12 +426,14 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
 // key16: the keys are 16-bit (tile ids of images with <= 65536 tiles): a quarter less traffic per pass; the
 // buffers are the same allocations, viewed as uint16_t.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
-                             int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16, hipStream_t s) {
+                             int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
+                             bool first_hist_done, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   if (key16)
     return sort_pairs_impl<uint16_t>(reinterpret_cast<uint16_t*>(keysA), valsA, reinterpret_cast<uint16_t*>(keysB),
-                                     valsB, sc, n, end_bit, start_in_A, is_depth_sort, s);
-  return sort_pairs_impl<uint32_t>(keysA, valsA, keysB, valsB, sc, n, end_bit, start_in_A, is_depth_sort, s);
+                                     valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done, s);
+  return sort_pairs_impl<uint32_t>(keysA, valsA, keysB, valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done,
+                                   s);
 }
 
 // Depth sort of the P (depth bits, Gaussian id) pairs: 32-bit keys, four 8-bit passes, FIVE launches
