@@ -11,7 +11,10 @@ constexpr int TILE = 16;             // tile edge in pixels (reference: config.h
 constexpr int SPLAT_F4 = 3;          // float4s per splat record (48 B)
 constexpr int GRAD_F4 = 3;           // float4s per per-instance gradient record (9 used of 12 floats)
 constexpr int PRE_BLOCK = 256;       // threads per block of the per-Gaussian kernels
-constexpr int SORT_TILE = 4096;      // pairs per workgroup tile of the radix sort (4 waves x 64 lanes x 16)
+constexpr int SORT_TILE = 4096;      // pairs per workgroup tile of the depth sort (4 waves x 64 lanes x 16)
+constexpr int TSORT_TILE = 4096;     // pairs per workgroup tile of the tile sort (8192 on 8 waves -- twice the run length
+                                     // per digit in the write-out -- measured the same: the pass is traffic-bound)
+constexpr int TSORT_WAVES = 4;
 constexpr int EMIT_CHUNK = 2048;     // instance slots emitted per workgroup
 constexpr int SORT_CHUNK = 64;       // workgroup tiles per scan chunk
 constexpr size_t ALIGN = 256;

@@ -552,11 +552,11 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
   for (int k = 0; k < 8; k++)
     if (t0 + (uint32_t)k < c1) atomicAdd(&hist[tk[k] & digit_mask0], 1u);
   }
-  // The sort's first pass needs per-4096-slot digit counts: two emitting workgroups share a sort tile, so each adds
+  // The sort's first pass needs digit counts per sort tile: several emitting workgroups share one, so each adds
   // its non-zero bins (k_scan_offsets cleared the array) -- this replaces a histogram pass over all the keys.
   __syncthreads();
   const uint32_t hc = hist[tid];
-  if (hc) atomicAdd(&counts0[(size_t)(c0 / SORT_TILE) * 256 + tid], hc);
+  if (hc) atomicAdd(&counts0[(size_t)(c0 / TSORT_TILE) * 256 + tid], hc);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -935,7 +935,7 @@ hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t 
 
 hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint2* ranges,
                                uint32_t* counts0, hipStream_t s) {
-  const size_t ncounts0 = (size_t)((R + SORT_TILE - 1) / SORT_TILE) * 256;
+  const size_t ncounts0 = (size_t)((R + TSORT_TILE - 1) / TSORT_TILE) * 256;
   ProfScope ps(K_SCAN_OFFSETS, s);
   hipLaunchKernelGGL(k_scan_offsets, dim3((fp.P + SCAN_TILE - 1) / SCAN_TILE), dim3(PRE_BLOCK), 0, s, fp, g, R,
                      chunk_first, ranges, counts0, ncounts0);

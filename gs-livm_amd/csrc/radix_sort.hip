@@ -64,7 +64,7 @@ __device__ __forceinline__ uint32_t block_excl_scan_256(uint32_t v, int lane, in
 
 // Per-tile digit counts with LDS integer atomics (order-independent, so still deterministic): three
 // instructions per key instead of a ballot match; neighbouring keys rarely share a digit in either sort.
-template <typename K>
+template <typename K, int TILE>
 __global__ __launch_bounds__(256) void k_sort_hist(const K* __restrict__ keys, int n, int shift, int nbits,
                                                    uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[256];
@@ -72,15 +72,15 @@ __global__ __launch_bounds__(256) void k_sort_hist(const K* __restrict__ keys, i
   const uint32_t mask = (1u << nbits) - 1u;
   hist[tid] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * SORT_TILE;
-  uint32_t key[SORT_TILE / 256];
+  const size_t base = (size_t)blockIdx.x * TILE;
+  uint32_t key[TILE / 256];
 #pragma unroll
-  for (int s = 0; s < SORT_TILE / 256; s++) {
+  for (int s = 0; s < TILE / 256; s++) {
     const size_t i = base + (size_t)s * 256 + tid;
     key[s] = i < (size_t)n ? (uint32_t)keys[i] : 0u;
   }
 #pragma unroll
-  for (int s = 0; s < SORT_TILE / 256; s++) {
+  for (int s = 0; s < TILE / 256; s++) {
     const size_t i = base + (size_t)s * 256 + tid;
     if (i < (size_t)n) atomicAdd(&hist[(key[s] >> shift) & mask], 1u);
   }
@@ -190,7 +190,6 @@ __global__ __launch_bounds__(64) void k_probe_lds_atomic_order(uint32_t* __restr
 
 // Status word of one (tile, digit) in the single-launch-per-pass sort: bit 31 = inclusive prefix over tiles
 // [0, tile] known, bit 30 = only this tile's own count known, low 30 bits = the count.
-constexpr int TSORT_WAVES = 4;  // waves per workgroup in the tile sort's scatter pass (8 measured 5 % slower)
 constexpr int LBK = 4;  // status words fetched per look-back round trip
 constexpr uint32_t ST_GLOBAL = 0x80000000u, ST_LOCAL = 0x40000000u, ST_MASK = 0x3FFFFFFFu;
 
@@ -203,7 +202,7 @@ constexpr uint32_t ST_GLOBAL = 0x80000000u, ST_LOCAL = 0x40000000u, ST_MASK = 0x
 // NW = waves per workgroup (4 or 8) sharing one 4096-pair tile.  With returning-atomic ranking VALU issue is only
 // 12 % of the pass (SQ counters) and 8 waves (twice the loads in flight per CU) did not help: at 331 MB algorithmic /
 // 380 MB measured traffic in 95 us the pass moves ~4 TB/s of mixed reads and 64-128-byte write runs.
-template <typename K, bool LB, bool ARANK, int NW>
+template <typename K, bool LB, bool ARANK, int NW, int TILE>
 __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ keys_in,
                                                       const uint32_t* __restrict__ vals_in,
                                                       K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
@@ -211,12 +210,12 @@ __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ 
                                                       const uint32_t* __restrict__ chunk_base,
                                                       const uint32_t* __restrict__ digit_total,
                                                       uint32_t* __restrict__ status, uint32_t* __restrict__ ticket) {
-  constexpr int NT = 64 * NW, WTILE = SORT_TILE / NW, NSTEP = WTILE / 64;
+  constexpr int NT = 64 * NW, WTILE = TILE / NW, NSTEP = WTILE / 64;
   __shared__ uint32_t wcnt[NW][256];  // per-wave digit counts, then per-wave local write bases
   __shared__ uint32_t gdelta[256];    // global position of local slot p holding digit d = gdelta[d] + p
   __shared__ uint32_t wtot[NW];
-  __shared__ K lkey[SORT_TILE];
-  __shared__ uint32_t lval[SORT_TILE];
+  __shared__ K lkey[TILE];
+  __shared__ uint32_t lval[TILE];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   int tile = blockIdx.x;
   if (LB) {
@@ -230,7 +229,7 @@ __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ 
   const uint32_t dbase = block_excl_scan_256(tid < 256 ? digit_total[tid] : 0u, lane, w, wtot);  // waves >= 4: unused
 #pragma unroll
   for (int k = 0; k < 4; k++) wcnt[w][lane + 64 * k] = 0;
-  const size_t base = (size_t)tile * SORT_TILE + (size_t)w * WTILE;
+  const size_t base = (size_t)tile * TILE + (size_t)w * WTILE;
   uint32_t key[NSTEP], val[NSTEP], lrank[NSTEP];
 #pragma unroll
   for (int s = 0; s < NSTEP; s++) {
@@ -345,10 +344,10 @@ __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ 
   }
   __syncthreads();
   // write-out: consecutive local slots of one digit are consecutive in the output
-  const size_t tile_base = (size_t)tile * SORT_TILE;
-  const uint32_t nvalid = (size_t)n - tile_base < (size_t)SORT_TILE ? (uint32_t)((size_t)n - tile_base) : SORT_TILE;
+  const size_t tile_base = (size_t)tile * TILE;
+  const uint32_t nvalid = (size_t)n - tile_base < (size_t)TILE ? (uint32_t)((size_t)n - tile_base) : TILE;
 #pragma unroll
-  for (int k = 0; k < SORT_TILE / NT; k++) {
+  for (int k = 0; k < TILE / NT; k++) {
     const uint32_t p = (uint32_t)(k * NT + tid);
     if (p < nvalid) {
       const uint32_t kk = (uint32_t)lkey[p];
@@ -383,7 +382,10 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
                                   int end_bit, bool start_in_A, bool is_depth_sort, bool first_hist_done,
                                   hipStream_t s) {
   const int kb = is_depth_sort ? (int)K_DSORT_HIST - (int)K_SORT_HIST : 0;  // profiler ids of this sort
-  const int ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+  // tile geometry of the instance sort (both key widths use the same today; see TSORT_TILE)
+  constexpr int TT = sizeof(K) == 2 ? TSORT_TILE : SORT_TILE, NWV = sizeof(K) == 2 ? TSORT_WAVES : 4;
+  if (sizeof(K) != 2) first_hist_done = false;  // the emitter counts per TSORT_TILE slots
+  const int ntiles = (n + TT - 1) / TT;
   const int nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
   const int passes = sort_passes(end_bit);
   const int nbits = sort_digit_bits(end_bit);
@@ -397,7 +399,7 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
     const int shift = nbits * p;
     if (!(p == 0 && first_hist_done)) {  // the emitter already left the first pass's counts in sc.counts
       ProfScope ps(K_SORT_HIST + kb, s);
-      hipLaunchKernelGGL(k_sort_hist<K>, dim3(ntiles), dim3(256), 0, s, kin, n, shift, nbits, sc.counts);
+      hipLaunchKernelGGL((k_sort_hist<K, TT>), dim3(ntiles), dim3(256), 0, s, kin, n, shift, nbits, sc.counts);
     }
     {
       ProfScope ps(K_SORT_SCAN_CHUNKS + kb, s);
@@ -410,11 +412,11 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
     {
       ProfScope ps(K_SORT_SCATTER + kb, s);
       if (arank)
-        hipLaunchKernelGGL((k_sort_scatter<K, false, true, TSORT_WAVES>), dim3(ntiles), dim3(64 * TSORT_WAVES), 0, s, kin, vin, kout, vout, n,
+        hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, n,
                            shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
       else
-        hipLaunchKernelGGL((k_sort_scatter<K, false, false, 4>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
+        hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, n,
                            shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
     }
@@ -456,11 +458,11 @@ hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
     uint32_t* kout = inA ? keysB : keysA;
     uint32_t* vout = inA ? valsB : valsA;
     if (arank)
-      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true, 4>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true, 4, SORT_TILE>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
                          8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     else
-      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false, 4>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout,
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false, 4, SORT_TILE>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout,
                          n, 8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     inA = !inA;

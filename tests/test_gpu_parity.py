@@ -266,6 +266,17 @@ def test_large_image_many_tile_bits(gpu_device):
     assert int(fr.ranges.max()) == fr.R and fr.ranges.shape[0] == 188 * 107
 
 
+def test_huge_image_32bit_tile_keys(gpu_device):
+    """4112 x 4112: 257 x 257 = 66049 tiles > 65536, so the tile sort runs on 32-bit keys (17 tile-id bits, three
+    passes) instead of the 16-bit path every other test takes."""
+    sc = S.make_scene(20_000, 4112, 4112, 23, sh_degree=0)
+    O.set_threads(min(O.max_threads(), 16))
+    fr = O.forward(sc, keep_handle=False, tight=True)
+    t, fwd = hip_forward(sc, gpu_device, debug=False)
+    check_forward(sc, fr, fwd, gpu_device, debug=False)
+    assert fr.ranges.shape[0] == 257 * 257 and int(fr.ranges.max()) == fr.R
+
+
 def test_tiny_images(gpu_device):
     for (W, H) in ((1, 1), (5, 3), (16, 16), (17, 1)):
         sc = S.make_scene(400, W, H, 19, sh_degree=1)
