@@ -1,12 +1,14 @@
-// preprocess.hip -- per-Gaussian stages of the MI355X rasterizer (gfx950):
-//   F1  k_preprocess        project / cull / EWA / SH->RGB, pack 48-B splat records, per-block tile sums
-//   F2  k_scan_block_sums   exclusive scan of per-block sums (+ total = num_rendered); used twice
-//   F3' k_depth_keys        point_offsets (id order) + (depth bits, id) pairs for the per-Gaussian depth sort
-//   F4  k_sorted_block_sums / k_emit   walk the Gaussians in depth order, assign each its run of instance
-//                           slots and emit (tile id, Gaussian id) pairs wave-cooperatively (coalesced)
-//   B2+B3 k_gaussian_backward  sum the per-instance gradient records of each Gaussian (no atomics,
-//        fixed order) and run the EWA / projection / SH / covariance chain rule in the same pass
-//   V1  k_mark_visible
+// preprocess.hip -- per-Gaussian and per-instance bookkeeping stages of the MI355X rasterizer (gfx950):
+//   F1  k_preprocess        project / cull / EWA / SH->RGB, footprint-box tile rectangle, 48-B splat record,
+//                           depth-sort pair; publishes num_rendered to the host mailbox (last workgroup)
+//   F3  k_scan_offsets      single-launch (look-back) scan of the tile counts in depth order; descriptors gathered
+//                           into depth order, slotinfo, emission chunk table
+//   F4  k_emit              output-centric emission of (tile id, Gaussian id) pairs in depth order (+ the digit
+//                           counts of the sort's first pass)
+//   B2a k_compact_touched / k_gather_records   per-Gaussian sums of the per-instance gradient records (no atomics,
+//                           fixed order)
+//   B2b k_gaussian_backward EWA / projection / SH / covariance chain rule
+//   V1  k_mark_visible;  debug only: k_point_offsets
 //
 // THIS FILE IS COMPILED WITH -ffp-contract=off.  radii, tile rectangles and the depth bits of the
 // sort keys are exact-match targets: every f32 operation below that feeds them is written in the

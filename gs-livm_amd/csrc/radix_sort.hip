@@ -10,18 +10,19 @@
 // is bit-identical, at roughly a quarter of the HBM traffic of six passes over R 12-byte pairs.
 //
 // Work unit: a workgroup tile of 4096 consecutive pairs = 4 waves x (64 lanes x 16 steps), lane =
-// consecutive element, so loads are 256-B coalesced.  Per pass (digit of <= 8 bits):
-//   k_sort_hist        per-tile digit counts                                   counts[tile][256]
-//   k_sort_scan_chunks exclusive prefix over the 64 tiles of a chunk (in place) + chunk_sums[chunk][256]
-//   k_sort_scan_top    one wave per digit: exclusive prefix over chunks (in place) + digit totals
-//   k_sort_scatter     ranks inside a 64-element step come from a wave-wide digit match (<= 8 ballots) +
-//                      popcount of lower lanes, per-wave running counts live in LDS; the tile is then
-//                      REORDERED IN LDS by digit and written out run by run, so global stores are
-//                      coalesced runs instead of 64 scattered dwords per instruction.
-// Every step is order-preserving (stable); no float atomics, no inter-workgroup communication inside a launch.
-// (A single-pass decoupled-look-back variant -- tile tickets, per-digit status words, sc1 relaxed loads -- was
-// built and measured in round 1: correct, but 0.66 ms vs 0.51 ms for the tile sort at C3, so it was dropped;
-// see DESIGN.md "Tried and rejected".)
+// consecutive element, so loads are coalesced.  The scatter kernel (k_sort_scatter) is shared by both sorts:
+//   * ranks inside a wave come from ONE returning LDS add per 64 elements on a per-wave digit table when the
+//     one-time probe k_probe_lds_atomic_order confirms lane-ordered conflict resolution (ARANK), otherwise from
+//     a wave-wide digit match (<= 8 ballots) + popcount of lower lanes;
+//   * the tile is then REORDERED IN LDS by digit and written out run by run, so global stores are coalesced
+//     runs instead of 64 scattered dwords per instruction.
+// Instance (tile-id) sort, R ~ 10^7 pairs, u16 keys: classic passes -- per-tile digit counts (from k_emit for
+//   the first pass, k_sort_hist after that), k_sort_scan_chunks / k_sort_scan_top, k_sort_scatter.
+// Depth sort, P ~ 10^6 pairs, u32 keys: k_sort_hist_all (all four digit histograms in one pass) and ONE launch
+//   per pass with decoupled look-back (LB): ticketed tiles, one status word per (tile, digit), counts published
+//   right after the key load.  For the 10^7-pair sort the look-back measured slower than the helper kernels
+//   (DESIGN.md "Tried and rejected"), for the 10^6-pair sort it replaces 16 launches by 5.
+// Every step is order-preserving (stable); no float atomics.
 #include <cstdlib>
 
 #include "gsr_internal.hpp"
