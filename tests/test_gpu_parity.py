@@ -277,6 +277,32 @@ def test_huge_image_32bit_tile_keys(gpu_device):
     assert fr.ranges.shape[0] == 257 * 257 and int(fr.ranges.max()) == fr.R
 
 
+def test_sort_fallback_without_lds_atomic_ranking(gpu_device):
+    """The radix scatter ranks with returning LDS atomics only after a one-time probe of the hardware's conflict
+    order; GSR_SORT_BALLOT_RANK=1 forces the ballot-match variant the library falls back to.  It is chosen at the
+    first launch of a process, so the check runs in a child process: bit-exact lists against the oracle there too."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch, gs_livm_amd as G\n"
+        "from gs_livm_amd import synthetic as S\n"
+        "from oracle import oracle as O\n"
+        "from helpers import hip_forward\n"
+        "sc = S.make_scene(40000, 500, 300, 6, sh_degree=1)\n"
+        "fr = O.forward(sc, tight=True)\n"
+        "t, fwd = hip_forward(sc, torch.device('cuda:0'))\n"
+        "v = G.state_views(fwd[5], fwd[6], fwd[7], 40000, fwd[0], 500, 300)\n"
+        "u = lambda x: x.cpu().numpy().view(np.uint32)\n"
+        "assert fwd[0] == fr.R and np.array_equal(u(v['point_list']), fr.point_list)\n"
+        "assert np.array_equal(u(v['ranges']), fr.ranges)\n"
+        "print('fallback ok')\n") % (os.path.dirname(GOLDEN.rstrip('/').rsplit('/', 1)[0]), os.path.dirname(GOLDEN))
+    env = dict(os.environ, GSR_SORT_BALLOT_RANK="1")
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "fallback ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_tiny_images(gpu_device):
     for (W, H) in ((1, 1), (5, 3), (16, 16), (17, 1)):
         sc = S.make_scene(400, W, H, 19, sh_degree=1)
