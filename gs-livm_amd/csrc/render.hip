@@ -163,8 +163,11 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
     hit = (a.x + c.z >= qx0) && (a.x - c.z <= qx0 + 7.0f) && (a.y + c.w >= qy0) && (a.y - c.w <= qy0 + 7.0f);
   }
   for (int base = 0; base < n && !wave_done; base += 64) {
-    sA[lane] = a;
-    sB[lane] = b;
+    // published conic terms carry the constant factors of power = -1/2 (A dx^2 + C dy^2) - B dx dy and the
+    // log2(e) of exp(x) = exp2(x log2 e): one multiply per ENTRY here instead of three per (entry, pixel) visit
+    constexpr float L2E = 1.4426950408889634f;
+    sA[lane] = make_float4(a.x, a.y, a.z * (-0.5f * L2E), a.w * (-L2E));
+    sB[lane] = make_float4(b.x * (-0.5f * L2E), b.y, b.z, b.w);
     sC[lane] = c;
     uint64_t m = __ballot(hit);
     // issue the next sub-chunk's gather now; it completes while this one is blended
@@ -181,8 +184,8 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
     // current hit is blended (two register sets, no copies), so their latency hides behind ~30 VALU ops.
     auto blend = [&](const float4 ra, const float4 rb, const float4 rc, const int jj) {
       const float dx = ra.x - pfx, dy = ra.y - pfy;
-      const float power = -0.5f * (ra.z * dx * dx + rb.x * dy * dy) - ra.w * dx * dy;
-      const float alpha = fminf(0.99f, rb.y * __expf(power));
+      const float power = ra.z * (dx * dx) + rb.x * (dy * dy) + ra.w * (dx * dy);  // = log2(e) x the reference's power
+      const float alpha = fminf(0.99f, rb.y * __builtin_amdgcn_exp2f(power));
       bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
       const float test_T = T * (1.0f - alpha);
       const bool stop = ok && (test_T < 0.0001f);
@@ -196,7 +199,6 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
       A += wgt;
       T = ok ? test_T : T;
       last = ok ? (uint32_t)(base + jj + 1) : last;
-      wave_done = __ballot(!done) == 0ull;
     };
     if (m) {
       int j0 = __builtin_ctzll(m), j1;
@@ -210,7 +212,10 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
           a1 = sA[j1]; b1 = sB[j1]; c1 = sC[j1];
         }
         blend(a0, b0, c0, j0);
-        if (wave_done || j1 < 0) break;
+        if (j1 < 0) {
+          wave_done = __ballot(!done) == 0ull;
+          break;
+        }
         j0 = -1;
         if (m) {
           j0 = __builtin_ctzll(m);
@@ -218,6 +223,7 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
           a0 = sA[j0]; b0 = sB[j0]; c0 = sC[j0];
         }
         blend(a1, b1, c1, j1);
+        wave_done = __ballot(!done) == 0ull;  // checked once per pair of visits: a visit after saturation changes nothing
         if (wave_done || j0 < 0) break;
       }
     }
