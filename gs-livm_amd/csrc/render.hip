@@ -283,6 +283,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
               dp2 = inside ? dL_dpix[2 * N + pid] : 0.f;
   const float dacc = inside ? dL_dacc[pid] : 0.f;  // the reference reads this unguarded (backward.cu:497)
   const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
+  const float neg_Tf_bg = -T_final * bg_dot;  // per-pixel constant of the background term (backward.cu:578-581)
   const float ddelx_dx = 0.5f * (float)fp.W, ddely_dy = 0.5f * (float)fp.H;
   float T = T_final;
   float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, aacc = 0.f;  // accum_rec, accum_acc_rec
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
           const float dch = alpha * T;
           float dL_dalpha = (b.z - ar0) * dp0 + (b.w - ar1) * dp1 + (blue - ar2) * dp2 + (1.0f - aacc) * dacc;
           dL_dalpha *= T;
-          dL_dalpha += (-T_final * rom) * bg_dot;
+          dL_dalpha += rom * neg_Tf_bg;
           // Fold this splat into the "everything behind the next one" accumulators NOW: the reference does the
           // same update at the top of its next iteration from saved (last_alpha, last_color) (backward.cu:533-543);
           // same operands, same expression, five fewer live registers and no state copies at the loop join.
@@ -362,13 +363,14 @@ __global__ __launch_bounds__(256) void k_blend_backward(
           aacc = __builtin_fmaf(oma, aacc, alpha);
           // Factors common to every pixel of the splat (opacity, -0.5, 0.5*W, 0.5*H) are applied once per
           // instance when the four quads are combined, not per pixel.
-          const float gdx = G * dx, gdy = G * dy;
-          const float sx = dL_dalpha * gdx, sy = dL_dalpha * gdy;
+          const float dLG = G * dL_dalpha;  // dL/dG up to the opacity factor; also the opacity partial itself
+          const float sx = dLG * dx, sy = dLG * dy;
           const float g0 = dch * dp0, g1 = dch * dp1, g2 = dch * dp2;
-          const float g3 = -sx * a.z - sy * a.w;  // dL_dalpha * dG_ddelx
-          const float g4 = -sy * b.x - sx * a.w;  // dL_dalpha * dG_ddely
+          // dL/dmean2D = -(conic . (sum sx, sum sy)): the conic is the same for every pixel of the splat, so the quads
+          // reduce sx and sy themselves and the 2x2 product is taken once per instance in the combine step
+          const float g3 = sx, g4 = sy;
           const float g5 = sx * dx, g6 = sx * dy, g7 = sy * dy;
-          float g8 = G * dL_dalpha;
+          float g8 = dLG;
           float w0, w1;
           wave_sum8(g0, g1, g2, g3, g4, g5, g6, g7, w0, w1);
           g8 = wave_sum_to_hi(g8);
@@ -400,10 +402,14 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       }
       if (any) {
         const size_t slot = sSlot[tid];
-        const float op = sB[tid].y;  // dL/dG = opacity * dL/dalpha; conic terms carry -0.5 (backward.cu:583-597)
+        const float4 ca = sA[tid];
+        const float4 cb = sB[tid];
+        const float op = cb.y;  // dL/dG = opacity * dL/dalpha; conic terms carry -0.5 (backward.cu:583-597)
         const float mx = op * ddelx_dx, my = op * ddely_dy, mc = -0.5f * op;
-        grad_inst[slot * GRAD_F4 + 0] = make_float4(s[0], s[1], s[2], s[3] * mx);
-        grad_inst[slot * GRAD_F4 + 1] = make_float4(s[4] * my, s[5] * mc, s[6] * mc, s[7] * mc);
+        const float gx = -(ca.z * s[3] + ca.w * s[4]);  // dG_ddelx, dG_ddely summed over the pixels (backward.cu:561-562)
+        const float gy = -(cb.x * s[4] + ca.w * s[3]);
+        grad_inst[slot * GRAD_F4 + 0] = make_float4(s[0], s[1], s[2], gx * mx);
+        grad_inst[slot * GRAD_F4 + 1] = make_float4(gy * my, s[5] * mc, s[6] * mc, s[7] * mc);
         grad_inst[slot * GRAD_F4 + 2] = make_float4(s[8], 0.f, 0.f, 0.f);
         inst_flag[slot] = 1;
         touched[sId[tid]] = 1;  // same value from every writer: a benign race
