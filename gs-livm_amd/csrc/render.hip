@@ -433,12 +433,7 @@ hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                  const float* dL_dpix, const float* dL_dacc, hipStream_t s) {
   ProfScope ps_k_blend_bwd(K_BLEND_BWD, s);
-  static const int bchunk = getenv("GSR_BCHUNK") ? atoi(getenv("GSR_BCHUNK")) : 128;  // experiment switch
-  if (bchunk == 64)
-    hipLaunchKernelGGL(k_blend_backward<64>, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, im.quad_last, b.point_list,
-                       g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst, b.inst_flag,
-                       g.touched);
-  else
+  // chunks of 128 list entries (64 and 128 measured equal, 256 slower: LDS footprint)
   hipLaunchKernelGGL(k_blend_backward<128>, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, im.quad_last, b.point_list,
                      g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst, b.inst_flag,
                      g.touched);
