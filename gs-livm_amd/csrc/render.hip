@@ -262,7 +262,9 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   __shared__ float sBlue[BCHUNK];
   __shared__ uint32_t sSlot[BCHUNK], sId[BCHUNK];
   __shared__ uint64_t smask[4][LW];
-  __shared__ __attribute__((aligned(8))) float sPart[4][BCHUNK][10];  // 9 used; 8-B aligned pairs
+  // per (quad, entry): 8 wave totals (four 8-B pairs) + the FOUR 16-lane-row partials of the ninth value: the
+  // rows are added in the combine step (once per instance) instead of two more cross-lane steps per visit
+  __shared__ __attribute__((aligned(8))) float sPart[4][BCHUNK][12];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tile = blockIdx.y * fp.gx + blockIdx.x;
   const uint32_t ql0 = quad_last_in[4 * tile], ql1 = quad_last_in[4 * tile + 1], ql2 = quad_last_in[4 * tile + 2],
@@ -328,7 +330,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
           if ((lane & 15) == 0) {
             float2* p2 = reinterpret_cast<float2*>(sPart[w][jj]);
             p2[lane >> 4] = make_float2(0.f, 0.f);
-            if (lane == 48) sPart[w][jj][8] = 0.f;
+            sPart[w][jj][8 + (lane >> 4)] = 0.f;
           }
           continue;
         }
@@ -373,16 +375,16 @@ __global__ __launch_bounds__(256) void k_blend_backward(
           float g8 = dLG;
           float w0, w1;
           wave_sum8(g0, g1, g2, g3, g4, g5, g6, g7, w0, w1);
-          g8 = wave_sum_to_hi(g8);
+          g8 = row_allsum(g8);
           if ((lane & 15) == 0) {  // lanes 0,16,32,48 hold the totals of (g0,g1),(g2,g3),(g4,g5),(g6,g7)
             float2* p2 = reinterpret_cast<float2*>(sPart[w][jj]);
             p2[lane >> 4] = make_float2(w0, w1);
+            sPart[w][jj][8 + (lane >> 4)] = g8;  // this row's share of the opacity partial
           }
-          if (lane == 63) sPart[w][jj][8] = g8;
         } else if ((lane & 15) == 0) {
           float2* p2 = reinterpret_cast<float2*>(sPart[w][jj]);
           p2[lane >> 4] = make_float2(0.f, 0.f);
-          if (lane == 48) sPart[w][jj][8] = 0.f;
+          sPart[w][jj][8 + (lane >> 4)] = 0.f;
         }
       }
     }
@@ -397,7 +399,8 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         if ((smask[q][lw] >> (tid & 63)) & 1ull) {
           any = true;
 #pragma unroll
-          for (int t = 0; t < 9; t++) s[t] += sPart[q][tid][t];
+          for (int t = 0; t < 8; t++) s[t] += sPart[q][tid][t];
+          s[8] += (sPart[q][tid][8] + sPart[q][tid][9]) + (sPart[q][tid][10] + sPart[q][tid][11]);
         }
       }
       if (any) {
