@@ -258,8 +258,9 @@ __global__ __launch_bounds__(256) void k_blend_backward(
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dacc, float4* __restrict__ grad_inst,
     uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched) {
   constexpr int LW = BCHUNK / 64;  // loader waves
-  __shared__ float4 sA[BCHUNK], sB[BCHUNK];
-  __shared__ float sBlue[BCHUNK];
+  // one 48-byte image per staged entry -- (x, y, conic.x, conic.y | conic.z, opacity, r, g | b, -, -, -) -- so a visit
+  // addresses all of it from ONE register (base + 48 jj) with immediate offsets
+  __shared__ float4 sE[BCHUNK][3];
   __shared__ uint32_t sSlot[BCHUNK], sId[BCHUNK];
   __shared__ uint64_t smask[4][LW];
   // per (quad, entry): 8 wave totals (four 8-B pairs) + the FOUR 16-lane-row partials of the ninth value: the
@@ -292,6 +293,9 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   // entries at or beyond the quad's own last contributor cannot receive gradient from this wave
   const int quad_last = (int)(w == 0 ? ql0 : w == 1 ? ql1 : w == 2 ? ql2 : ql3);
 
+  // this lane's pair slot (first 8 floats) and row slot (last 4) inside an entry's 12 floats
+  float* const my_pair = &sPart[w][0][0] + 2 * (lane >> 4);
+  float* const my_row = &sPart[w][0][0] + 8 + (lane >> 4);
   for (int base = 0; base < n; base += BCHUNK) {
     const int k = base + tid;  // k-th entry counted from the back of [0, n)
     const bool stager = tid < BCHUNK;
@@ -304,9 +308,9 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       const float4 c = splats[(size_t)id * SPLAT_F4 + 2];
       const uint2 si = slotinfo[id];
       const int x0 = (int)(si.y & 1023u), y0 = (int)((si.y >> 10) & 1023u), rw = (int)(si.y >> 20);
-      sA[tid] = a;
-      sB[tid] = b;
-      sBlue[tid] = c.x;
+      sE[tid][0] = a;
+      sE[tid][1] = b;
+      sE[tid][2] = make_float4(c.x, 0.f, 0.f, 0.f);
       sId[tid] = id;
       sSlot[tid] = si.x + (uint32_t)(((int)blockIdx.y - y0) * rw + ((int)blockIdx.x - x0));
       hits = quad_hits(a.x, a.y, c.z, c.w, tx0, ty0);
@@ -328,15 +332,14 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         const int pos = n - 1 - (base + jj);  // 0-based index in the tile list == `contributor` after decrement
         if (pos >= quad_last) {                // wave-uniform: nothing to do for this quad, publish zeros
           if ((lane & 15) == 0) {
-            float2* p2 = reinterpret_cast<float2*>(sPart[w][jj]);
-            p2[lane >> 4] = make_float2(0.f, 0.f);
-            sPart[w][jj][8 + (lane >> 4)] = 0.f;
+            *reinterpret_cast<float2*>(my_pair + 12u * (uint32_t)jj) = make_float2(0.f, 0.f);
+            my_row[12u * (uint32_t)jj] = 0.f;
           }
           continue;
         }
-        const float4 a = sA[jj];
-        const float4 b = sB[jj];
-        const float blue = sBlue[jj];
+        const float4 a = sE[jj][0];
+        const float4 b = sE[jj][1];
+        const float blue = sE[jj][2].x;
         const float dx = a.x - pfx, dy = a.y - pfy;
         const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
         const float Graw = __expf(power);
@@ -377,14 +380,12 @@ __global__ __launch_bounds__(256) void k_blend_backward(
           wave_sum8(g0, g1, g2, g3, g4, g5, g6, g7, w0, w1);
           g8 = row_allsum(g8);
           if ((lane & 15) == 0) {  // lanes 0,16,32,48 hold the totals of (g0,g1),(g2,g3),(g4,g5),(g6,g7)
-            float2* p2 = reinterpret_cast<float2*>(sPart[w][jj]);
-            p2[lane >> 4] = make_float2(w0, w1);
-            sPart[w][jj][8 + (lane >> 4)] = g8;  // this row's share of the opacity partial
+            *reinterpret_cast<float2*>(my_pair + 12u * (uint32_t)jj) = make_float2(w0, w1);
+            my_row[12u * (uint32_t)jj] = g8;  // this row's share of the opacity partial
           }
         } else if ((lane & 15) == 0) {
-          float2* p2 = reinterpret_cast<float2*>(sPart[w][jj]);
-          p2[lane >> 4] = make_float2(0.f, 0.f);
-          sPart[w][jj][8 + (lane >> 4)] = 0.f;
+          *reinterpret_cast<float2*>(my_pair + 12u * (uint32_t)jj) = make_float2(0.f, 0.f);
+          my_row[12u * (uint32_t)jj] = 0.f;
         }
       }
     }
@@ -405,8 +406,8 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       }
       if (any) {
         const size_t slot = sSlot[tid];
-        const float4 ca = sA[tid];
-        const float4 cb = sB[tid];
+        const float4 ca = sE[tid][0];
+        const float4 cb = sE[tid][1];
         const float op = cb.y;  // dL/dG = opacity * dL/dalpha; conic terms carry -0.5 (backward.cu:583-597)
         const float mx = op * ddelx_dx, my = op * ddely_dy, mc = -0.5f * op;
         const float gx = -(ca.z * s[3] + ca.w * s[4]);  // dG_ddelx, dG_ddely summed over the pixels (backward.cu:561-562)
