@@ -360,6 +360,7 @@ static void blend_tile(gsro_frame* f, int tx, int ty, const float* bg) {
       float T = 1.0f, C[3] = {0, 0, 0}, Dp = 0, A = 0;
       uint32_t contributor = 0, last = 0;
       uint8_t fragile = 0;
+      float t_unc = 0.0f;
       for (uint32_t i = b; i < e; i++) {
         contributor++;
         uint32_t g = f->point_list[i];
@@ -373,10 +374,16 @@ static void blend_tile(gsro_frame* f, int tx, int ty, const float* bg) {
          * 1/255 alpha cut, the T < 1e-4 stop (T carries accumulated error) and power > 0.  A flip
          * there legitimately changes the pixel by up to alpha*T, so parity tests compare such
          * pixels with the looser bound. */
-        if (fabsf(alpha * 255.0f - 1.0f) < 2e-5f || fabsf(power) < 1e-6f) fragile = 1;
+        /* The power is a quadratic form whose three terms can cancel (a nearly singular conic along its long
+         * axis, hundreds of pixels from the centre: terms of 1e3 summing to ~5): its f32 rounding uncertainty is
+         * ~ a few ulp of the LARGEST term, and alpha inherits it as a RELATIVE error (alpha = op * e^power).  The
+         * window of the alpha cut and of power > 0 therefore scales with that uncertainty. */
+        float unc = 6e-7f * (fabsf(co[0] * dx * dx) + fabsf(co[2] * dy * dy) + 2.0f * fabsf(co[1] * dx * dy));
+        if (fabsf(alpha * 255.0f - 1.0f) < 2e-5f + unc || fabsf(power) < 1e-6f + unc) fragile = 1;
         if (alpha < 1.0f / 255.0f) continue;
         float test_T = T * (1 - alpha);
-        if (fabsf(test_T * 10000.0f - 1.0f) < 2e-4f) fragile = 1;
+        t_unc += alpha * unc / (1.0f - alpha); /* relative uncertainty T inherits from the alphas before it */
+        if (fabsf(test_T * 10000.0f - 1.0f) < 2e-4f + t_unc) fragile = 1;
         if (test_T < 0.0001f) break; /* done = true */
         for (int ch = 0; ch < 3; ch++) C[ch] += feat[3 * g + ch] * alpha * T;
         Dp += f->depths[g] * alpha * T; /* forward.cu:386 */

@@ -26,7 +26,7 @@ import torch
 
 import gs_livm_amd as G
 from gs_livm_amd import synthetic as S
-from helpers import grad_close, hip_backward, hip_forward, to_dev
+from helpers import conic_condition, grad_close, hip_backward, hip_forward, to_dev
 from oracle import oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -42,7 +42,7 @@ def _u32(t):
     return t.cpu().numpy().view(np.uint32)
 
 
-def check_forward(sc, fr, fwd, dev, debug=True):
+def check_forward(sc, fr, fwd, dev, debug=True, max_fragile=5e-3):
     """Every stage of the forward against an oracle frame (or a golden fixture exposing the same fields)."""
     R, color, depth, acc, radii, geom, binning, img = fwd
     P, W, H = sc["means3D"].shape[0], sc["W"], sc["H"]
@@ -72,7 +72,7 @@ def check_forward(sc, fr, fwd, dev, debug=True):
         assert np.array_equal(_u32(v["point_list"]), fr.point_list)
     assert np.array_equal(_u32(v["ranges"]), fr.ranges)               # THE bit-exact target of BASELINE
     frag = fr.fragile > 0
-    assert frag.mean() < 5e-3
+    assert frag.mean() < max_fragile
     nc, fT = _u32(v["n_contrib"]), v["final_T"].cpu().numpy()
     assert np.array_equal(nc[~frag], fr.n_contrib[~frag])
     for name, got, ref in (("color", color, fr.out_color), ("depth", depth, fr.out_depth), ("acc", acc, fr.out_acc),
@@ -192,16 +192,17 @@ def _variant(P=1500, W=200, H=120, seed=13, D=1):
     return S.make_scene(P, W, H, seed, sh_degree=D)
 
 
-def _full_check(sc, dev, seed=13):
+def _full_check(sc, dev, seed=13, stress=False):
     fr = O.forward(sc, tight=True)
     t, fwd = hip_forward(sc, dev)
-    check_forward(sc, fr, fwd, dev)
+    check_forward(sc, fr, fwd, dev, max_fragile=2e-2 if stress else 5e-3)  # needles widen the uncertainty windows
     dcol, dacc = masked_grads(sc["W"], sc["H"], seed, fr.fragile)
     O.set_threads(1)
     ref = O.backward(fr, sc, dcol, dacc)
     got = hip_backward(sc, t, fwd, dcol, dacc, dev)
+    cond = conic_condition(fr.conic_opacity) if stress else None
     for k in GRAD_NAMES:
-        grad_close(got[k], ref[k], k)
+        grad_close(got[k], ref[k], k, cond=cond)
     return fr, got
 
 
@@ -301,6 +302,29 @@ def test_sort_fallback_without_lds_atomic_ranking(gpu_device):
     env = dict(os.environ, GSR_SORT_BALLOT_RANK="1")
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fallback ok" in out.stdout, out.stderr[-2000:]
+
+
+def test_randomised_scenes(gpu_device):
+    """Twelve seeded random configurations -- image size, field of view, camera yaw / position, SH degree, Gaussian
+    count, anisotropy and opacity ranges, background, scale modifier, non-unit quaternions -- through the full
+    forward + backward comparison: integer stages bit-exact, images to 1e-4, gradients to the conditioning-aware
+    bound of helpers.grad_close (the scenes contain nearly singular conics and screen-filling splats)."""
+    rng = np.random.default_rng(20240611)
+    for case in range(12):
+        W, H = int(rng.integers(17, 700)), int(rng.integers(9, 420))
+        P = int(rng.integers(50, 30_000))
+        D = int(rng.integers(0, 4))
+        seed = 1000 + case
+        g = S.make_gaussians(P, seed, sh_degree=D, fovx_deg=float(rng.uniform(35, 100)), aspect=W / H,
+                             zmin=float(rng.uniform(0.3, 2.0)), zmax=float(rng.uniform(3.0, 60.0)))
+        cam = S.make_camera(W, H, fovx_deg=float(rng.uniform(35, 100)), yaw_deg=float(rng.uniform(-25, 25)),
+                            position=tuple(rng.uniform(-0.5, 0.5, 3)))
+        sc = dict(g, **cam, bg=rng.uniform(0, 1, 3).astype(np.float32), colors_precomp=None, cov3D_precomp=None,
+                  scale_modifier=float(rng.uniform(0.5, 1.5)))
+        sc["scales"] = (sc["scales"] * rng.uniform(0.5, 2.0, (P, 3))).astype(np.float32)      # stronger anisotropy
+        sc["rotations"] = (sc["rotations"] * rng.uniform(0.5, 2.0, (P, 1))).astype(np.float32)  # used as given (A.3)
+        sc["opacities"] = rng.uniform(0.0, 1.0, (P, 1)).astype(np.float32) ** float(rng.uniform(0.5, 3.0))
+        _full_check(sc, gpu_device, seed=seed, stress=True)
 
 
 def test_tiny_images(gpu_device):
