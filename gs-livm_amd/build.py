@@ -34,7 +34,8 @@ UNITS = {
     "growth.hip": [],
     "api.hip": [],
 }
-HEADERS = [os.path.join(CSRC, "gsr_internal.hpp"), os.path.join(ROOT, "include", "gsraster.h")]
+HEADERS = [os.path.join(CSRC, "gsr_internal.hpp"), os.path.join(CSRC, "sort_core.hpp"),
+           os.path.join(ROOT, "include", "gsraster.h")]
 
 
 def _stale(out, deps):
