@@ -54,8 +54,11 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
         # order + gpack gather in; soff, sn, srect, sinv out; slotinfo for the Gaussians with instances
         "k_scan_offsets": P * 12 + P * 16 + P_vis * 8,
         # tile ids are 16-bit when the image has <= 65536 tiles (kb bytes per key), Gaussian ids 32-bit
-        "k_emit": R * (kb + 4) + P_vis * 16,
-        "k_sort_hist": R * kb, "k_sort_scatter": R * 2 * (kb + 4),  # (tile, id): read + write per pass
+        # 16-bit tile ids: the emitter only counts digits and clears flags (the pairs are generated inside the first
+        # sort pass, which therefore reads descriptors instead of pairs): per-launch AVERAGE of the two scatter passes
+        "k_emit": (R * 1 + P_vis * 16) if kb == 2 else (R * (kb + 4) + P_vis * 16),
+        "k_sort_hist": R * kb,
+        "k_sort_scatter": (R * (kb + 4) * 3 + P_vis * 16) // 2 if kb == 2 else R * 2 * (kb + 4),
         "k_tile_ranges": R * kb + tiles * 8,
         "k_sort_scan_chunks": (R // 4096 + 1) * 2048, "k_sort_scan_top": 0,
         "k_blend_forward": R * 44 + W * H * 28,                   # full lists (early exit reads fewer)

@@ -268,9 +268,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const bool key16 = tiles <= 65536;  // tile ids fit 16 bits for every image up to 4096 x 4096
   STAGE(launch_scan_offsets(fp, g, R, b.chunk_first, im.ranges, b.tsort.counts, stream));
   STAGE(launch_emit(fp, g, R, b.chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB,
-                    b.inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16, stream));
+                    b.inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16,
+                    /*store_pairs=*/!key16, stream));  // 16-bit keys: the pairs are generated inside the first sort pass
+  const EmitFusion ef = {fp, g, R, b.chunk_first};
   STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, R, tile_bits, start_in_A,
-                          /*is_depth_sort=*/false, key16, /*first_hist_done=*/true, stream));
+                          /*is_depth_sort=*/false, key16, /*first_hist_done=*/true, key16 ? &ef : nullptr, stream));
   STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, key16, stream));
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
   return R;

@@ -210,14 +210,24 @@ hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, int R, uint32
                                uint32_t* counts0, hipStream_t s);
 hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
                        uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_mask0, bool key16,
-                       hipStream_t s);
+                       bool store_pairs, hipStream_t s);
+// what k_emit_scatter (the tile sort's first pass with the pairs generated in place) needs from the emitter's side
+struct EmitFusion {
+  FrameParams fp;
+  GeomState g;
+  int R;
+  const uint32_t* chunk_first;
+};
+hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_t* vals_out, int nbits0,
+                               const uint32_t* counts, const uint32_t* chunk_base, const uint32_t* digit_total,
+                               bool arank, hipStream_t s);
 hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningState b, float* dL_dmean2D,
                                  float* dL_dconic, float* dL_dopacity, float* dL_dcolor, hipStream_t s);
 // Stable LSD radix sort of n (u32, u32) pairs on key bits [0, end_bit); buffers ping-pong between
 // (keysA, valsA) and (keysB, valsB), starting in A when start_in_A.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
                              int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
-                             bool first_hist_done, hipStream_t s);
+                             bool first_hist_done, const EmitFusion* fused_first_pass, hipStream_t s);
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
                              int n, hipStream_t s);
 hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, bool key16, hipStream_t s);

@@ -16,6 +16,7 @@
 // rounding matches the unfused CPU oracle bit for bit.  Divisions and sqrt are IEEE (hipcc default
 // -fhip-fp32-correctly-rounded-divide-sqrt).
 #include "gsr_internal.hpp"
+#include "sort_core.hpp"
 
 namespace gsr {
 
@@ -471,7 +472,127 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
   if (i0 + SCAN_ITEMS >= fp.P) g.soff[fp.P] = off;  // sentinel: = R
 }
 
-template <typename K>
+// Staging and slot walk of the emitters, as device functions (k_emit_scatter runs them twice per workgroup).
+struct EmitStage {
+  uint32_t s_off[EMIT_CHUNK + 2], s_id[EMIT_CHUNK + 1], s_rect[EMIT_CHUNK + 1], s_inv[EMIT_CHUNK + 1];
+};
+
+// descriptors of the Gaussians covering slots [c0, c1) of emit chunk `e` -> LDS; returns their count S
+__device__ __forceinline__ int emit_stage(const GeomState& g, const uint32_t* __restrict__ chunk_first, int e,
+                                          uint32_t c1, int R, int tid, EmitStage& st) {
+  const int i0 = (int)chunk_first[e];
+  int i1 = (int)chunk_first[e + 1];
+  if (c1 < (uint32_t)R && g.soff[i1] >= c1) i1--;  // the Gaussian covering slot c1 starts exactly there
+  const int S = i1 - i0 + 1;                        // <= EMIT_CHUNK + 1: every staged Gaussian owns >= 1 slot
+  for (int j = tid; j <= S; j += 256) {             // s_off[S] = start of the first run beyond this chunk
+    st.s_off[j] = g.soff[i0 + j];
+    if (j < S) {
+      st.s_id[j] = g.order[i0 + j];
+      st.s_rect[j] = g.srect[i0 + j];
+      st.s_inv[j] = g.sinv[i0 + j];
+    }
+  }
+  return S;
+}
+
+// (tile id, Gaussian id) of the eight slots [t0, t0 + 8); those >= c1 are meaningless
+__device__ __forceinline__ void emit_walk8(uint32_t t0, uint32_t c1, int S, const EmitStage& st, uint32_t gx,
+                                           uint32_t tk[8], uint32_t iv[8]) {
+  int lo = 0, hi = S - 1;  // largest j with s_off[j] <= t0
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (st.s_off[mid] <= t0) lo = mid; else hi = mid - 1;
+  }
+  int j = lo;
+  uint32_t rc = st.s_rect[j], rw = rc >> 20, id = st.s_id[j], next = st.s_off[j + 1];
+  const uint32_t local = t0 - st.s_off[j];
+  // local < 2^20, rw < 2^10  =>  local * (inv*rw - 2^32) < 2^32: the multiply-high quotient is exact
+  uint32_t row = rw == 1u ? local : __umulhi(local, st.s_inv[j]);
+  uint32_t col = local - row * rw;
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    tk[k] = (((rc >> 10) & 1023u) + row) * gx + (rc & 1023u) + col;
+    iv[k] = id;
+    const uint32_t t = t0 + (uint32_t)k + 1u;
+    if (t == next && t < c1) {  // run finished: next Gaussian (every staged Gaussian owns >= 1 slot)
+      j++;
+      rc = st.s_rect[j]; rw = rc >> 20; id = st.s_id[j]; next = st.s_off[j + 1];
+      row = 0; col = 0;
+    } else if (++col == rw) {
+      col = 0;
+      row++;
+    }
+  }
+}
+
+// Emission fused with the FIRST pass of the tile sort (16-bit keys): a workgroup generates the 4096 pairs of one
+// sort tile (two emit chunks), brings them into scatter order through LDS and scatters them by their low digit --
+// the unsorted pairs are never written to or read back from HBM (2 x 6 bytes per instance).  The digit counts the
+// scatter needs were accumulated by the count-only emitter (k_emit<K, false>) and scanned in between.
+template <bool ARANK>
+__global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, GeomState g, const int R,
+                                                      const uint32_t* __restrict__ chunk_first,
+                                                      uint16_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                      const int nbits0, const uint32_t* __restrict__ counts,
+                                                      const uint32_t* __restrict__ chunk_base,
+                                                      const uint32_t* __restrict__ digit_total) {
+  static_assert(TSORT_TILE == 2 * EMIT_CHUNK && TSORT_WAVES == 4, "one sort tile = two emit chunks on 256 threads");
+  constexpr int NSTEP = TSORT_TILE / TSORT_WAVES / 64;
+  union SMem {
+    EmitStage st;                                         // while generating
+    ScatterLds<uint16_t, TSORT_WAVES, TSORT_TILE> L;      // afterwards
+  };
+  __shared__ SMem sm;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int tile = blockIdx.x;
+  uint32_t tk[2][8], iv[2][8];
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const int e = 2 * tile + r;
+    const uint32_t c0 = (uint32_t)e * EMIT_CHUNK;
+    const bool live = c0 < (uint32_t)R;  // workgroup-uniform
+    const uint32_t c1 = c0 + EMIT_CHUNK < (uint32_t)R ? c0 + EMIT_CHUNK : (uint32_t)R;
+    int S = 0;
+    if (live) S = emit_stage(g, chunk_first, e, c1, R, tid, sm.st);
+    __syncthreads();
+    const uint32_t t0 = c0 + (uint32_t)tid * 8u;
+    if (live && t0 < c1) emit_walk8(t0, c1, S, sm.st, (uint32_t)fp.gx, tk[r], iv[r]);
+    __syncthreads();
+  }
+  // slot order -> LDS (the staging arrays are dead now)
+#pragma unroll
+  for (int r = 0; r < 2; r++) {
+    const uint32_t sl = (uint32_t)r * EMIT_CHUNK + (uint32_t)tid * 8u;  // slot inside the tile
+    const size_t t0 = (size_t)tile * TSORT_TILE + sl;
+    if (t0 + 8 <= (size_t)R) {
+      *reinterpret_cast<uint4*>(sm.L.lkey + sl) = make_uint4(tk[r][0] | (tk[r][1] << 16), tk[r][2] | (tk[r][3] << 16),
+                                                             tk[r][4] | (tk[r][5] << 16), tk[r][6] | (tk[r][7] << 16));
+      *reinterpret_cast<uint4*>(sm.L.lval + sl) = make_uint4(iv[r][0], iv[r][1], iv[r][2], iv[r][3]);
+      *reinterpret_cast<uint4*>(sm.L.lval + sl + 4) = make_uint4(iv[r][4], iv[r][5], iv[r][6], iv[r][7]);
+    } else {
+      for (int k = 0; k < 8 && t0 + k < (size_t)R; k++) {
+        sm.L.lkey[sl + k] = (uint16_t)tk[r][k];
+        sm.L.lval[sl + k] = iv[r][k];
+      }
+    }
+  }
+  __syncthreads();
+  // scatter order -> registers
+  uint32_t key[NSTEP], val[NSTEP];
+#pragma unroll
+  for (int s = 0; s < NSTEP; s++) {
+    const uint32_t p = (uint32_t)(w * (TSORT_TILE / TSORT_WAVES) + s * 64 + lane);
+    const bool valid = (size_t)tile * TSORT_TILE + p < (size_t)R;
+    key[s] = valid ? (uint32_t)sm.L.lkey[p] : 0u;
+    val[s] = valid ? sm.L.lval[p] : 0u;
+  }
+  __syncthreads();
+  scatter_core<uint16_t, false, ARANK, TSORT_WAVES, TSORT_TILE>(sm.L, key, val, tile, keys_out, vals_out, R, 0, nbits0,
+                                                                counts, chunk_base, digit_total, nullptr);
+}
+
+// STORE = false: count-only emitter in front of k_emit_scatter (digit counts + inst_flag reset, no pair stores)
+template <typename K, bool STORE>
 __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g, const int R,
                                               const uint32_t* __restrict__ chunk_first,
                                               K* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out,
@@ -530,7 +651,13 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
       row++;
     }
   }
-  if (t0 + 8u <= c1) {
+  if (!STORE) {
+    if (t0 + 8u <= c1) {
+      *reinterpret_cast<uint2*>(inst_flag + t0) = make_uint2(0u, 0u);
+    } else {
+      for (int k = 0; k < 8 && t0 + (uint32_t)k < c1; k++) inst_flag[t0 + k] = 0;
+    }
+  } else if (t0 + 8u <= c1) {
     uint4* vo = reinterpret_cast<uint4*>(ivals_out + t0);
     if (sizeof(K) == 2) {  // eight 16-bit tile ids = one 16-byte store
       *reinterpret_cast<uint4*>(tkeys_out + t0) = make_uint4(tk[0] | (tk[1] << 16), tk[2] | (tk[3] << 16),
@@ -946,16 +1073,33 @@ hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, int R, uint32
 
 hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
                        uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_mask0, bool key16,
-                       hipStream_t s) {
+                       bool store_pairs, hipStream_t s) {
   if (R <= 0) return hipSuccess;
   ProfScope ps(K_EMIT, s);
   const dim3 grid((R + EMIT_CHUNK - 1) / EMIT_CHUNK);
-  if (key16)
-    hipLaunchKernelGGL(k_emit<uint16_t>, grid, dim3(256), 0, s, fp, g, R, chunk_first,
+  if (key16 && store_pairs)
+    hipLaunchKernelGGL((k_emit<uint16_t, true>), grid, dim3(256), 0, s, fp, g, R, chunk_first,
+                       reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_mask0);
+  else if (key16)
+    hipLaunchKernelGGL((k_emit<uint16_t, false>), grid, dim3(256), 0, s, fp, g, R, chunk_first,
                        reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_mask0);
   else
-    hipLaunchKernelGGL(k_emit<uint32_t>, grid, dim3(256), 0, s, fp, g, R, chunk_first, tkeys_out, ivals_out,
+    hipLaunchKernelGGL((k_emit<uint32_t, true>), grid, dim3(256), 0, s, fp, g, R, chunk_first, tkeys_out, ivals_out,
                        inst_flag, counts0, digit_mask0);
+  return hipGetLastError();
+}
+
+// first pass of the 16-bit tile sort with the pairs generated in place (see k_emit_scatter)
+hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_t* vals_out, int nbits0,
+                               const uint32_t* counts, const uint32_t* chunk_base, const uint32_t* digit_total,
+                               bool arank, hipStream_t s) {
+  const dim3 grid((ef.R + TSORT_TILE - 1) / TSORT_TILE);
+  if (arank)
+    hipLaunchKernelGGL(k_emit_scatter<true>, grid, dim3(256), 0, s, ef.fp, ef.g, ef.R, ef.chunk_first, keys_out, vals_out,
+                       nbits0, counts, chunk_base, digit_total);
+  else
+    hipLaunchKernelGGL(k_emit_scatter<false>, grid, dim3(256), 0, s, ef.fp, ef.g, ef.R, ef.chunk_first, keys_out,
+                       vals_out, nbits0, counts, chunk_base, digit_total);
   return hipGetLastError();
 }
 

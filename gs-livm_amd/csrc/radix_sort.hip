@@ -179,7 +179,7 @@ static bool lds_atomic_rank_ok(hipStream_t s) {
 template <typename K>
 static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t* valsB, SortScratch sc, int n,
                                   int end_bit, bool start_in_A, bool is_depth_sort, bool first_hist_done,
-                                  hipStream_t s) {
+                                  const EmitFusion* ef, hipStream_t s) {
   const int kb = is_depth_sort ? (int)K_DSORT_HIST - (int)K_SORT_HIST : 0;  // profiler ids of this sort
   // tile geometry of the instance sort (both key widths use the same today; see TSORT_TILE)
   constexpr int TT = sizeof(K) == 2 ? TSORT_TILE : SORT_TILE, NWV = sizeof(K) == 2 ? TSORT_WAVES : 4;
@@ -208,7 +208,12 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
       ProfScope ps(K_SORT_SCAN_TOP + kb, s);
       hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, sc.chunk_sums, nchunks, sc.digit_base);
     }
-    {
+    if (p == 0 && ef && sizeof(K) == 2) {  // the emitter generates the pairs inside the first pass
+      ProfScope ps(K_SORT_SCATTER + kb, s);
+      const hipError_t e = launch_emit_scatter(*ef, reinterpret_cast<uint16_t*>(kout), vout, nbits, sc.counts,
+                                               sc.chunk_sums, sc.digit_base, arank, s);
+      if (e != hipSuccess) return e;
+    } else {
       ProfScope ps(K_SORT_SCATTER + kb, s);
       if (arank)
         hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, n,
@@ -228,13 +233,13 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
 // buffers are the same allocations, viewed as uint16_t.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
                              int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
-                             bool first_hist_done, hipStream_t s) {
+                             bool first_hist_done, const EmitFusion* fused_first_pass, hipStream_t s) {
   if (n <= 0) return hipSuccess;
   if (key16)
     return sort_pairs_impl<uint16_t>(reinterpret_cast<uint16_t*>(keysA), valsA, reinterpret_cast<uint16_t*>(keysB),
-                                     valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done, s);
+                                     valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done, fused_first_pass, s);
   return sort_pairs_impl<uint32_t>(keysA, valsA, keysB, valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done,
-                                   s);
+                                   nullptr, s);
 }
 
 // Depth sort of the P (depth bits, Gaussian id) pairs: 32-bit keys, four 8-bit passes, FIVE launches
