@@ -28,6 +28,8 @@ def load(dirname, counter):
             kn = kn[5:]
         if r["Counter_Name"] == counter and kn.startswith("gsr::"):
             name = kn.split("(")[0].replace("gsr::", "").split("<")[0]
+            if name == "k_emit_scatter":  # the tile sort's first pass (pairs generated in place): same profiler id
+                name = "k_sort_scatter"
             if name == "k_sort_hist_all":  # the depth sort's all-digit histogram: bench.py calls it by its profiler id
                 name = "k_sort_hist[depth]"
             d[name].append((float(r["Counter_Value"]), int(r["Grid_Size"])))
