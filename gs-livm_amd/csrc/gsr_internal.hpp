@@ -101,7 +101,6 @@ struct GeomState {
   uint32_t* dkeysB;
   uint32_t* dvalsB;
   uint32_t* soff;           // [P+1] first instance slot of order[i] (exclusive scan in depth order); soff[P] = R
-  uint32_t* sn;             // [P] tiles_touched of order[i]
   uint32_t* srect;          // [P] packed tile rect of order[i]: x0 | y0 << 10 | width << 20
   uint32_t* sinv;           // [P] ceil(2^32 / width) of order[i] (exact division by multiply-high)
   uint8_t* touched;         // [P] 1 = the blend backward wrote at least one gradient record for this Gaussian
@@ -125,7 +124,6 @@ struct GeomState {
     g.dkeysB = c.take<uint32_t>(P);
     g.dvalsB = c.take<uint32_t>(P);
     g.soff = c.take<uint32_t>(P + 1);
-    g.sn = c.take<uint32_t>(P);
     g.srect = c.take<uint32_t>(P);
     g.sinv = c.take<uint32_t>(P);
     g.touched = c.take<uint8_t>(P);

@@ -348,7 +348,7 @@ __global__ __launch_bounds__(1024) void k_point_offsets(const int P, const uint3
 //
 // k_scan_offsets: ONE launch for the exclusive scan in depth order (decoupled look-back over workgroups of
 // 4096 Gaussians: ticketed tiles, one 64-bit status word each, wave-wide look-back window) that also
-//   * gathers (tiles_touched, rect) into depth order with one 8-byte load per Gaussian (sn, srect, sinv are
+//   * gathers (tiles_touched, rect) into depth order with one 8-byte load per Gaussian (srect, sinv are
 //     then read coalesced by k_emit), writes slotinfo for the backward,
 //   * writes, for every EMIT_CHUNK boundary inside a Gaussian's run, the depth-order index of that
 //     Gaussian (chunk_first: saves k_emit two dependent searches per workgroup),
@@ -455,7 +455,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
     for (int q = 0; q < SCAN_ITEMS / 4; q++) {
       const int j = 4 * q;
       *reinterpret_cast<uint4*>(g.soff + i0 + j) = make_uint4(offs[j], offs[j + 1], offs[j + 2], offs[j + 3]);
-      *reinterpret_cast<uint4*>(g.sn + i0 + j) = make_uint4(n[j], n[j + 1], n[j + 2], n[j + 3]);
       *reinterpret_cast<uint4*>(g.srect + i0 + j) = make_uint4(rect[j], rect[j + 1], rect[j + 2], rect[j + 3]);
       *reinterpret_cast<uint4*>(g.sinv + i0 + j) = make_uint4(inv[j], inv[j + 1], inv[j + 2], inv[j + 3]);
     }
@@ -464,7 +463,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
     for (int k = 0; k < SCAN_ITEMS; k++)
       if (i0 + k < fp.P) {
         g.soff[i0 + k] = offs[k];
-        g.sn[i0 + k] = n[k];
         g.srect[i0 + k] = rect[k];
         g.sinv[i0 + k] = inv[k];
       }
@@ -598,59 +596,20 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
                                               K* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out,
                                               uint8_t* __restrict__ inst_flag, uint32_t* __restrict__ counts0,
                                               const uint32_t digit_mask0) {
-  __shared__ uint32_t s_off[EMIT_CHUNK + 2], s_id[EMIT_CHUNK + 1], s_rect[EMIT_CHUNK + 1], s_inv[EMIT_CHUNK + 1];
+  __shared__ EmitStage st;
   __shared__ uint32_t hist[256];  // digit counts of the tile sort's FIRST pass for this workgroup's 2048 slots
   const int tid = threadIdx.x;
   hist[tid] = 0;
   const uint32_t c0 = (uint32_t)blockIdx.x * EMIT_CHUNK;
   const uint32_t c1 = c0 + EMIT_CHUNK < (uint32_t)R ? c0 + EMIT_CHUNK : (uint32_t)R;
-  // i0 = Gaussian covering slot c0; i1 = last Gaussian whose run starts before c1
-  const int i0 = (int)chunk_first[blockIdx.x];
-  int i1 = (int)chunk_first[blockIdx.x + 1];
-  if (c1 < (uint32_t)R && g.soff[i1] >= c1) i1--;  // the Gaussian covering slot c1 starts exactly there
-  const int S = i1 - i0 + 1;  // <= EMIT_CHUNK + 1: every visible Gaussian owns >= 1 slot
-  for (int j = tid; j <= S; j += 256) {  // s_off[S] = start of the first run beyond this chunk (soff has P+1 entries)
-    s_off[j] = g.soff[i0 + j];
-    if (j < S) {
-      s_id[j] = g.order[i0 + j];
-      s_rect[j] = g.srect[i0 + j];
-      s_inv[j] = g.sinv[i0 + j];
-    }
-  }
+  const int S = emit_stage(g, chunk_first, (int)blockIdx.x, c1, R, tid, st);
   __syncthreads();
   // Each thread owns EIGHT consecutive slots: one bisection for the first, then it walks (row, col) and steps to
   // the next Gaussian when a run ends -- 4x fewer LDS round trips than a search per slot, 32-byte stores.
   const uint32_t t0 = c0 + (uint32_t)tid * 8u;
   if (t0 < c1) {
-  int j = 0;
-  {
-    int lo = 0, hi = S - 1;  // largest j with s_off[j] <= t0
-    while (lo < hi) {
-      const int mid = (lo + hi + 1) >> 1;
-      if (s_off[mid] <= t0) lo = mid; else hi = mid - 1;
-    }
-    j = lo;
-  }
-  uint32_t rc = s_rect[j], rw = rc >> 20, id = s_id[j], next = s_off[j + 1];
-  uint32_t local = t0 - s_off[j];
-  // local < 2^20, rw < 2^10  =>  local * (inv*rw - 2^32) < 2^32: the multiply-high quotient is exact
-  uint32_t row = rw == 1u ? local : __umulhi(local, s_inv[j]);
-  uint32_t col = local - row * rw;
   uint32_t tk[8], iv[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) {
-    tk[k] = (((rc >> 10) & 1023u) + row) * (uint32_t)fp.gx + (rc & 1023u) + col;
-    iv[k] = id;
-    const uint32_t t = t0 + (uint32_t)k + 1u;
-    if (t == next && t < c1) {  // run finished: next Gaussian (every staged Gaussian owns >= 1 slot)
-      j++;
-      rc = s_rect[j]; rw = rc >> 20; id = s_id[j]; next = s_off[j + 1];
-      row = 0; col = 0;
-    } else if (++col == rw) {
-      col = 0;
-      row++;
-    }
-  }
+  emit_walk8(t0, c1, S, st, (uint32_t)fp.gx, tk, iv);
   if (!STORE) {
     if (t0 + 8u <= c1) {
       *reinterpret_cast<uint2*>(inst_flag + t0) = make_uint2(0u, 0u);
