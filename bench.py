@@ -51,7 +51,7 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
         "k_preprocess": P * (44 + 12 * M) + P * 25 + P_vis * 77,
         "k_point_offsets": P * 8,                                 # debug forwards only
         "k_sort_hist[depth]": P * 4, "k_sort_scatter[depth]": P * 16,
-        # order + gpack gather in; soff, sn, srect, sinv out; slotinfo for the Gaussians with instances
+        # order + gpack gather in; 16-byte depth-ordered descriptor out; slotinfo for the Gaussians with instances
         "k_scan_offsets": P * 12 + P * 16 + P_vis * 8,
         # tile ids are 16-bit when the image has <= 65536 tiles (kb bytes per key), Gaussian ids 32-bit
         # 16-bit tile ids: the emitter only counts digits and clears flags (the pairs are generated inside the first

@@ -100,9 +100,10 @@ struct GeomState {
   uint32_t* dkeysA;         // [P] depth-sort ping-pong buffers
   uint32_t* dkeysB;
   uint32_t* dvalsB;
-  uint32_t* soff;           // [P+1] first instance slot of order[i] (exclusive scan in depth order); soff[P] = R
-  uint32_t* srect;          // [P] packed tile rect of order[i]: x0 | y0 << 10 | width << 20
-  uint32_t* sinv;           // [P] ceil(2^32 / width) of order[i] (exact division by multiply-high)
+  uint4* sdesc;             // [P+1] the emitters' descriptor of order[i], ONE 16-byte load each:
+                            //   x = first instance slot (exclusive scan in depth order; sdesc[P].x = R),
+                            //   y = Gaussian id, z = packed tile rect x0 | y0 << 10 | width << 20,
+                            //   w = ceil(2^32 / width) (exact division by multiply-high)
   uint8_t* touched;         // [P] 1 = the blend backward wrote at least one gradient record for this Gaussian
   uint32_t* tlist;          // [P] compacted ids of touched Gaussians (backward); count in total[2]
   DepthSortScratch dsort;
@@ -123,9 +124,7 @@ struct GeomState {
     g.dkeysA = c.take<uint32_t>(P);
     g.dkeysB = c.take<uint32_t>(P);
     g.dvalsB = c.take<uint32_t>(P);
-    g.soff = c.take<uint32_t>(P + 1);
-    g.srect = c.take<uint32_t>(P);
-    g.sinv = c.take<uint32_t>(P);
+    g.sdesc = c.take<uint4>(P + 1);
     g.touched = c.take<uint8_t>(P);
     g.tlist = c.take<uint32_t>(P);
     DepthSortScratch::carve(c, P, g.dsort);

@@ -341,15 +341,15 @@ __global__ __launch_bounds__(1024) void k_point_offsets(const int P, const uint3
 // ------------------------------------------------------------------------------------------------
 // F4.  Replaces duplicateWithKeys (reference rasterizer_impl.cu:64-101) and the InclusiveSum before it.
 // Gaussians are visited in depth order; Gaussian order[i] gets the contiguous slot run
-// [soff[i], soff[i+1]) and its instances are emitted in the reference's row-major tile order with
+// [sdesc[i].x, sdesc[i+1].x) and its instances are emitted in the reference's row-major tile order with
 // key = tile id, value = Gaussian id.  The depth part of the reference's 64-bit key is implied by the
 // emission order, which the stable tile sort preserves.  A slot is also the index of the instance's
 // gradient record in the backward.
 //
 // k_scan_offsets: ONE launch for the exclusive scan in depth order (decoupled look-back over workgroups of
 // 4096 Gaussians: ticketed tiles, one 64-bit status word each, wave-wide look-back window) that also
-//   * gathers (tiles_touched, rect) into depth order with one 8-byte load per Gaussian (srect, sinv are
-//     then read coalesced by k_emit), writes slotinfo for the backward,
+//   * gathers (tiles_touched, rect) into depth order with one 8-byte load per Gaussian and writes the 16-byte
+//     descriptor (slot, id, rect, 1/width) the emitters read coalesced, one load each; slotinfo for the backward,
 //   * writes, for every EMIT_CHUNK boundary inside a Gaussian's run, the depth-order index of that
 //     Gaussian (chunk_first: saves k_emit two dependent searches per workgroup),
 //   * zeroes the tile ranges (the reference's cudaMemset, rasterizer_impl.cu:311).
@@ -450,24 +450,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
     }
     off += n[k];
   }
-  if (i0 + SCAN_ITEMS <= fp.P) {
 #pragma unroll
-    for (int q = 0; q < SCAN_ITEMS / 4; q++) {
-      const int j = 4 * q;
-      *reinterpret_cast<uint4*>(g.soff + i0 + j) = make_uint4(offs[j], offs[j + 1], offs[j + 2], offs[j + 3]);
-      *reinterpret_cast<uint4*>(g.srect + i0 + j) = make_uint4(rect[j], rect[j + 1], rect[j + 2], rect[j + 3]);
-      *reinterpret_cast<uint4*>(g.sinv + i0 + j) = make_uint4(inv[j], inv[j + 1], inv[j + 2], inv[j + 3]);
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++)
-      if (i0 + k < fp.P) {
-        g.soff[i0 + k] = offs[k];
-        g.srect[i0 + k] = rect[k];
-        g.sinv[i0 + k] = inv[k];
-      }
-  }
-  if (i0 + SCAN_ITEMS >= fp.P) g.soff[fp.P] = off;  // sentinel: = R
+  for (int k = 0; k < SCAN_ITEMS; k++)
+    if (i0 + k < fp.P) g.sdesc[i0 + k] = make_uint4(offs[k], id[k], rect[k], inv[k]);  // 256 contiguous bytes per thread
+  if (i0 + SCAN_ITEMS >= fp.P) g.sdesc[fp.P] = make_uint4(off, 0u, 0u, 0u);  // sentinel: .x = R
 }
 
 // Staging and slot walk of the emitters, as device functions (k_emit_scatter runs them twice per workgroup).
@@ -480,14 +466,15 @@ __device__ __forceinline__ int emit_stage(const GeomState& g, const uint32_t* __
                                           uint32_t c1, int R, int tid, EmitStage& st) {
   const int i0 = (int)chunk_first[e];
   int i1 = (int)chunk_first[e + 1];
-  if (c1 < (uint32_t)R && g.soff[i1] >= c1) i1--;  // the Gaussian covering slot c1 starts exactly there
-  const int S = i1 - i0 + 1;                        // <= EMIT_CHUNK + 1: every staged Gaussian owns >= 1 slot
-  for (int j = tid; j <= S; j += 256) {             // s_off[S] = start of the first run beyond this chunk
-    st.s_off[j] = g.soff[i0 + j];
+  if (c1 < (uint32_t)R && g.sdesc[i1].x >= c1) i1--;  // the Gaussian covering slot c1 starts exactly there
+  const int S = i1 - i0 + 1;                          // <= EMIT_CHUNK + 1: every staged Gaussian owns >= 1 slot
+  for (int j = tid; j <= S; j += 256) {               // s_off[S] = start of the first run beyond this chunk
+    const uint4 d = g.sdesc[i0 + j];                  // (sdesc has P + 1 entries)
+    st.s_off[j] = d.x;
     if (j < S) {
-      st.s_id[j] = g.order[i0 + j];
-      st.s_rect[j] = g.srect[i0 + j];
-      st.s_inv[j] = g.sinv[i0 + j];
+      st.s_id[j] = d.y;
+      st.s_rect[j] = d.z;
+      st.s_inv[j] = d.w;
     }
   }
   return S;
