@@ -266,7 +266,15 @@ def main():
         v = G.state_views(fw[5], fw[6], fw[7], P, R, W, H)
         ln = (v["ranges"][:, 1] - v["ranges"][:, 0]).float()
         R_bwd = int(v["quad_last"].long().max(1).values.sum())
-        stats = dict(P=P, P_vis=P_vis, R=R, R_walked_by_backward=R_bwd, tiles=int(ln.numel()),
+        # instance count of the REFERENCE's binning (getRect on the 3-sigma radius, auxiliary.h:46-57) for the same
+        # frame: the footprint-box culling emits fewer; SURVEY.md 8(d)'s whole-path formula is stated on this one
+        vis = radii > 0
+        px, py, rr = v["splats"][vis, 0], v["splats"][vis, 1], radii[vis].float()
+        gx, gy = (W + 15) // 16, (H + 15) // 16
+        x0 = ((px - rr) / 16).trunc().clamp(0, gx); x1 = ((px + rr + 15) / 16).trunc().clamp(0, gx)
+        y0 = ((py - rr) / 16).trunc().clamp(0, gy); y1 = ((py + rr + 15) / 16).trunc().clamp(0, gy)
+        R_ref = int(((x1 - x0) * (y1 - y0)).double().sum())
+        stats = dict(P=P, P_vis=P_vis, R=R, R_reference_binning=R_ref, R_walked_by_backward=R_bwd, tiles=int(ln.numel()),
                      mean_tile_list=float(ln.mean()), max_tile_list=int(ln.max()),
                      mean_contrib_per_pixel=float(v["n_contrib"].float().mean()))
     tiles = stats["tiles"]
@@ -313,6 +321,15 @@ def main():
     b_path = sum(alg.get(k, 0) * d["launches_per_step"] for k, d in kernels.items())
     raster_ms = sum(k["ms_per_step"] for k in kernels.values())
 
+    # SURVEY.md 8(d)'s whole-path figure, as written there: the bytes the REFERENCE's algorithm moves for this
+    # frame (its instance count, 64-bit keys, ceil((32+bit)/8) sort passes, grad zero-fill) over this path's time
+    n_pass = (32 + tile_bits + 7) // 8
+    Rr = stats["R_reference_binning"]
+    b_ref_fwd = (P * (44 + 12 * M) + P * 8 + P_vis * 67 + P * 8 + P * 20 + Rr * 12 + Rr * 24 * n_pass + Rr * 8
+                 + tiles * 8 + Rr * 44 + W * H * 28)
+    b_ref_bwd = (W * H * 24 + Rr * 40 + Rr * 36 + P * (108 + 12 * M) + P_vis * (111 + 12 * M) + P_vis * (64 + 12 * M))
+    b_ref = b_ref_fwd + (0 if args.forward_only else b_ref_bwd)
+
     ms_per_step = elapsed / args.steps * 1e3
     mpix = n_gpus * W * H * args.steps / elapsed / 1e6
     out = {
@@ -334,7 +351,11 @@ def main():
         "fps": round(1e3 / ms_per_step * n_gpus, 2),
         "roofline": roofline,
         "whole_path": {"kernel_ms_per_step": round(raster_ms, 4), "algorithmic_GB_per_step": round(b_path / 1e9, 3),
-                       "alg_GBps_over_kernel_time": round(b_path / (raster_ms * 1e-3) / 1e9, 1) if raster_ms else None},
+                       "alg_GBps_over_kernel_time": round(b_path / (raster_ms * 1e-3) / 1e9, 1) if raster_ms else None,
+                       # the reference algorithm's bytes for the same frame (formula of SURVEY.md 8(d)) / step time
+                       "reference_algorithm_GB_per_step": round(b_ref / 1e9, 3), "sort_passes_reference": n_pass,
+                       "reference_algorithm_GBps": round(b_ref / (ms_per_step * 1e-3) / 1e9, 1),
+                       "reference_algorithm_frac_of_peak": round(b_ref / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)},
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in d.items()}
                     for k, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         "workload_stats": stats,

@@ -63,6 +63,12 @@ struct SortScratch {  // scratch of one radix sort over n (u32 key, u32 value) p
 constexpr int PRE_SUB = 4;      // 256-Gaussian blocks walked by one k_preprocess workgroup
 constexpr int SCAN_ITEMS = 16;                    // consecutive Gaussians per thread in k_scan_offsets
 constexpr int SCAN_TILE = PRE_BLOCK * SCAN_ITEMS;  // 4096
+// Workgroup tile of the depth sort's scatter passes: maps of up to 128 k Gaussians get 1024-pair tiles so a pass
+// still spreads over the chip (measured: 48 -> 35 us for the four passes at 10 k; slower from ~300 k up, where the
+// longer look-back chain costs more than the wider spread gains).
+constexpr int SORT_TILE_SMALL = 1024;
+inline size_t depth_sort_tile(size_t n) { return n <= ((size_t)1 << 17) ? SORT_TILE_SMALL : SORT_TILE; }
+
 struct DepthSortScratch {
   uint32_t* words;
   size_t nwords;
@@ -76,7 +82,7 @@ struct DepthSortScratch {
     return reinterpret_cast<unsigned long long*>(words + scan_off);
   }
   static void carve(Carver& c, size_t n, DepthSortScratch& s) {
-    const size_t ntiles = (n + SORT_TILE - 1) / SORT_TILE;
+    const size_t ntiles = (n + depth_sort_tile(n) - 1) / depth_sort_tile(n);
     const size_t nscan = (n + SCAN_TILE - 1) / SCAN_TILE;
     s.scan_off = 1088 + 4 * ntiles * 256;  // even: the 64-bit status words are 8-byte aligned
     s.nwords = s.scan_off + 2 * nscan;

@@ -37,10 +37,50 @@ __global__ __launch_bounds__(256) void k_activate(const int P, const int M, cons
   const float inv = 1.0f / nrm;
   rotations[4 * i] = q.x * inv; rotations[4 * i + 1] = q.y * inv; rotations[4 * i + 2] = q.z * inv;
   rotations[4 * i + 3] = q.w * inv;
-  float* o = shs + (size_t)i * M * 3;
-  o[0] = f_dc[3 * i]; o[1] = f_dc[3 * i + 1]; o[2] = f_dc[3 * i + 2];
-  const float* r = f_rest + (size_t)i * (M - 1) * 3;
-  for (int k = 0; k < (M - 1) * 3; k++) o[3 + k] = r[k];
+  if (M == 1) {  // shs = f_dc; longer rows are moved by k_sh_move
+    shs[3 * i] = f_dc[3 * i]; shs[3 * i + 1] = f_dc[3 * i + 1]; shs[3 * i + 2] = f_dc[3 * i + 2];
+  }
+}
+
+// M > 1: shs = cat(f_dc, f_rest, 1) (SPLIT = false) or its adjoint, the split of dL/dshs into the two leaves'
+// gradients (SPLIT = true), as a flat copy: a thread owns 4 consecutive floats of the [P][M][3] side (one
+// 16-byte access when aligned) and walks the matching elements of the [P][1][3] / [P][M-1][3] side, which are
+// consecutive except at the row seams -- every wave instruction covers one contiguous span either way.
+template <bool SPLIT>
+__global__ __launch_bounds__(256) void k_sh_move(const unsigned long long numel, const int C, float* __restrict__ wide,
+                                                 float* __restrict__ f_dc, float* __restrict__ f_rest, const int al) {
+  const unsigned long long e0 = ((unsigned long long)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (e0 >= numel) return;
+  unsigned long long n;
+  int c;
+  if (numel <= 0xFFFFFFFFull) { const uint32_t q = (uint32_t)e0 / (uint32_t)C; n = q; c = (int)((uint32_t)e0 - q * (uint32_t)C); }
+  else { n = e0 / (unsigned long long)C; c = (int)(e0 - n * (unsigned long long)C); }
+  const int cnt = numel - e0 < 4 ? (int)(numel - e0) : 4;
+  float v[4] = {0.f, 0.f, 0.f, 0.f};
+  if (SPLIT) {
+    if (al && cnt == 4) { const float4 t = *reinterpret_cast<const float4*>(wide + e0); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else for (int k = 0; k < cnt; k++) v[k] = wide[e0 + k];
+  }
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    if (k < cnt) {
+      float* leaf = c < 3 ? f_dc + n * 3 + c : f_rest + n * (unsigned long long)(C - 3) + (c - 3);
+      if (SPLIT) *leaf = v[k]; else v[k] = *leaf;
+      if (++c == C) { c = 0; n++; }
+    }
+  }
+  if (!SPLIT) {
+    if (al && cnt == 4) *reinterpret_cast<float4*>(wide + e0) = make_float4(v[0], v[1], v[2], v[3]);
+    else for (int k = 0; k < cnt; k++) wide[e0 + k] = v[k];
+  }
+}
+
+template <bool SPLIT>
+static void launch_sh_move(int P, int M, float* wide, float* f_dc, float* f_rest, hipStream_t s) {
+  const unsigned long long numel = (unsigned long long)P * 3ull * (unsigned long long)M;
+  const unsigned long long groups = (numel + 3) / 4;
+  hipLaunchKernelGGL(k_sh_move<SPLIT>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, numel, 3 * M, wide, f_dc,
+                     f_rest, (reinterpret_cast<uintptr_t>(wide) & 15u) == 0 ? 1 : 0);
 }
 
 __global__ __launch_bounds__(256) void k_activate_backward(
@@ -70,10 +110,9 @@ __global__ __launch_bounds__(256) void k_activate_backward(
   }
   g_rotation_raw[4 * i] = o.x; g_rotation_raw[4 * i + 1] = o.y; g_rotation_raw[4 * i + 2] = o.z;
   g_rotation_raw[4 * i + 3] = o.w;
-  const float* gs = g_shs + (size_t)i * M * 3;
-  g_f_dc[3 * i] = gs[0]; g_f_dc[3 * i + 1] = gs[1]; g_f_dc[3 * i + 2] = gs[2];
-  float* r = g_f_rest + (size_t)i * (M - 1) * 3;
-  for (int k = 0; k < (M - 1) * 3; k++) r[k] = gs[3 + k];
+  if (M == 1) {  // longer rows are split by k_sh_move
+    g_f_dc[3 * i] = g_shs[3 * i]; g_f_dc[3 * i + 1] = g_shs[3 * i + 1]; g_f_dc[3 * i + 2] = g_shs[3 * i + 2];
+  }
 }
 
 struct AdamArgs {
@@ -263,10 +302,94 @@ __global__ __launch_bounds__(256) void k_model_step(const StepArgs a) {
       *reinterpret_cast<float4*>(a.a_scales + e0) = make_float4(expf(p.x), expf(p.y), expf(p.z), expf(p.w));
     if (t == 5 && a.a_opac)
       *reinterpret_cast<float4*>(a.a_opac + e0) = make_float4(sigmoidf_(p.x), sigmoidf_(p.y), sigmoidf_(p.z), sigmoidf_(p.w));
+  } else if (left >= 4 && ((a.aligned >> t) & 1u) && (t == 1 || t == 2) && a.numel[t] <= 0xFFFFFFF0ull) {
+    // SH tensors at M > 1: parameter and moments are contiguous (16-byte accesses); the gradient and the
+    // activated copy live inside shs [P][M][3] -- 4 dword accesses each, consecutive except where the 4
+    // elements cross into the next Gaussian's row.  One 32-bit division per thread (step_elem does three
+    // 64-bit ones per element).
+    const uint32_t W = t == 1 ? 3u : 3u * (uint32_t)(a.M - 1), C = 3u * (uint32_t)a.M, skip = t == 1 ? 0u : 3u;
+    uint32_t n = (uint32_t)e0 / W, r = (uint32_t)e0 - n * W;
+    unsigned long long si[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      si[k] = (unsigned long long)n * C + skip + r;
+      if (++r == W) { r = 0; n++; }
+    }
+    float4 p = *reinterpret_cast<float4*>(P_[t] + e0);
+    float4 m = *reinterpret_cast<float4*>(a.m[t] + e0);
+    float4 v = *reinterpret_cast<float4*>(a.v[t] + e0);
+    const float g0 = a.g_shs[si[0]], g1 = a.g_shs[si[1]], g2 = a.g_shs[si[2]], g3 = a.g_shs[si[3]];
+    p.x = adam_update(p.x, g0, m.x, v.x, a, t);
+    p.y = adam_update(p.y, g1, m.y, v.y, a, t);
+    p.z = adam_update(p.z, g2, m.z, v.z, a, t);
+    p.w = adam_update(p.w, g3, m.w, v.w, a, t);
+    *reinterpret_cast<float4*>(P_[t] + e0) = p;
+    *reinterpret_cast<float4*>(a.m[t] + e0) = m;
+    *reinterpret_cast<float4*>(a.v[t] + e0) = v;
+    if (a.a_shs) { a.a_shs[si[0]] = p.x; a.a_shs[si[1]] = p.y; a.a_shs[si[2]] = p.z; a.a_shs[si[3]] = p.w; }
   } else {
     const int cnt = left < 4 ? (int)left : 4;
     for (int k = 0; k < cnt; k++) step_elem(a, t, e0 + k);
   }
+}
+
+// k_sh_step: the SH part of the tail at M > 1.  The two leaves ([P][1][3] and [P][M-1][3]) and their moments are
+// contiguous per tensor, the gradient and the activated copy are rows of shs [P][M][3]: a workgroup takes SH_ROWS
+// Gaussians, brings their dL/dshs rows into LDS as one contiguous block, updates the leaves with 16-byte
+// accesses (gradient read from / new value written to the LDS rows) and stores the rows back out as the next
+// forward's shs -- every global access is a coalesced 16-byte one.  Needs 16-byte-aligned tensors; otherwise
+// k_model_step's generic path does the same arithmetic.
+__device__ __forceinline__ void sh_leaf_step(const StepArgs& a, const int t, float* buf, float* __restrict__ p_,
+                                             float* __restrict__ m_, float* __restrict__ v_, const int count,
+                                             const int W, const int C, const int skip) {
+  const int n4 = count >> 2;
+  for (int j = threadIdx.x; j < n4; j += 256) {
+    float4 p = reinterpret_cast<float4*>(p_)[j], m = reinterpret_cast<float4*>(m_)[j], v = reinterpret_cast<float4*>(v_)[j];
+    int n = (4 * j) / W, r = 4 * j - n * W;
+    int li[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      li[k] = n * C + skip + r;
+      if (++r == W) { r = 0; n++; }
+    }
+    p.x = adam_update(p.x, buf[li[0]], m.x, v.x, a, t);
+    p.y = adam_update(p.y, buf[li[1]], m.y, v.y, a, t);
+    p.z = adam_update(p.z, buf[li[2]], m.z, v.z, a, t);
+    p.w = adam_update(p.w, buf[li[3]], m.w, v.w, a, t);
+    reinterpret_cast<float4*>(p_)[j] = p; reinterpret_cast<float4*>(m_)[j] = m; reinterpret_cast<float4*>(v_)[j] = v;
+    buf[li[0]] = p.x; buf[li[1]] = p.y; buf[li[2]] = p.z; buf[li[3]] = p.w;
+  }
+  const int e = 4 * n4 + (int)threadIdx.x;  // the last partial group of the last workgroup
+  if (e < count) {
+    const int n = e / W, li = n * C + skip + (e - n * W);
+    float p = p_[e], m = m_[e], v = v_[e];
+    p = adam_update(p, buf[li], m, v, a, t);
+    p_[e] = p; m_[e] = m; v_[e] = v;
+    buf[li] = p;
+  }
+}
+
+constexpr int SH_ROWS = 64;  // 12 KB of LDS at M = 16: eight workgroups per CU keep loads, arithmetic and stores overlapped
+
+__global__ __launch_bounds__(256) void k_sh_step(const StepArgs a) {
+  extern __shared__ float sh_buf[];  // [nrows][3M]
+  const int C = 3 * a.M, W = C - 3;
+  const size_t row0 = (size_t)blockIdx.x * SH_ROWS;
+  const int nrows = a.P - (long long)row0 < SH_ROWS ? (int)(a.P - (long long)row0) : SH_ROWS;
+  const int n = nrows * C, n4 = n >> 2;
+  const float* gsrc = a.g_shs + row0 * C;
+  for (int j = threadIdx.x; j < n4; j += 256)
+    reinterpret_cast<float4*>(sh_buf)[j] = reinterpret_cast<const float4*>(gsrc)[j];
+  if (4 * n4 + (int)threadIdx.x < n) sh_buf[4 * n4 + threadIdx.x] = gsrc[4 * n4 + threadIdx.x];
+  __syncthreads();
+  sh_leaf_step(a, 1, sh_buf, a.fdc + row0 * 3, a.m[1] + row0 * 3, a.v[1] + row0 * 3, nrows * 3, 3, C, 0);
+  sh_leaf_step(a, 2, sh_buf, a.frest + row0 * W, a.m[2] + row0 * W, a.v[2] + row0 * W, nrows * W, W, C, 3);
+  if (!a.a_shs) return;  // uniform
+  __syncthreads();
+  float* dst = a.a_shs + row0 * C;
+  for (int j = threadIdx.x; j < n4; j += 256)
+    reinterpret_cast<float4*>(dst)[j] = reinterpret_cast<const float4*>(sh_buf)[j];
+  if (4 * n4 + (int)threadIdx.x < n) dst[4 * n4 + threadIdx.x] = sh_buf[4 * n4 + threadIdx.x];
 }
 
 hipError_t launch_model_step(int P, int M, float* const* params, float* const* exp_avg, float* const* exp_avg_sq,
@@ -295,15 +418,21 @@ hipError_t launch_model_step(int P, int M, float* const* params, float* const* e
   unsigned long long cum = 0;
   a.aligned = 0;
   for (int k = 0; k < 6; k++) {
-    a.numel[k] = ne[k];
-    cum += (ne[k] + 3) / 4;
-    a.end[k] = cum;
     const uintptr_t bits = (uintptr_t)params[k] | (uintptr_t)exp_avg[k] | (uintptr_t)exp_avg_sq[k] |
                            (uintptr_t)extra[k][0] | (uintptr_t)extra[k][1];
     if ((bits & 15u) == 0) a.aligned |= 1u << k;
   }
+  // M > 1: the SH leaves go through k_sh_step (LDS-staged rows) when everything it touches is 16-byte aligned
+  const size_t sh_lds = (size_t)SH_ROWS * 3 * (size_t)M * sizeof(float);
+  const bool sh_staged = M > 1 && P > 0 && ((a.aligned >> 1) & 3u) == 3u && sh_lds <= 64 * 1024;
+  for (int k = 0; k < 6; k++) {
+    a.numel[k] = (sh_staged && (k == 1 || k == 2)) ? 0ull : ne[k];
+    cum += (a.numel[k] + 3) / 4;
+    a.end[k] = cum;
+  }
   ProfScope ps(K_MODEL_STEP, s);
   hipLaunchKernelGGL(k_model_step, dim3((unsigned)((cum + 255) / 256)), dim3(256), 0, s, a);
+  if (sh_staged) hipLaunchKernelGGL(k_sh_step, dim3((unsigned)((P + SH_ROWS - 1) / SH_ROWS)), dim3(256), sh_lds, s, a);
   return hipGetLastError();
 }
 
@@ -313,6 +442,7 @@ hipError_t launch_activate(int P, int M, const float* scaling_raw, const float* 
   ProfScope ps(K_ACTIVATE, s);
   hipLaunchKernelGGL(k_activate, dim3((P + 255) / 256), dim3(256), 0, s, P, M, scaling_raw, rotation_raw, opacity_raw,
                      f_dc, f_rest, scales, rotations, opacities, shs);
+  if (M > 1 && P > 0) launch_sh_move<false>(P, M, shs, const_cast<float*>(f_dc), const_cast<float*>(f_rest), s);
   return hipGetLastError();
 }
 
@@ -325,6 +455,7 @@ hipError_t launch_activate_backward(int P, int M, const float* rotation_raw, con
   hipLaunchKernelGGL(k_activate_backward, dim3((P + 255) / 256), dim3(256), 0, s, P, M, rotation_raw, scales,
                      opacities, g_scales, g_rot, g_opac, g_shs, g_scaling_raw, g_rotation_raw, g_opacity_raw, g_f_dc,
                      g_f_rest);
+  if (M > 1 && P > 0) launch_sh_move<true>(P, M, const_cast<float*>(g_shs), g_f_dc, g_f_rest, s);
   return hipGetLastError();
 }
 

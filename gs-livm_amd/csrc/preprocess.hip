@@ -130,8 +130,72 @@ __device__ __forceinline__ Ewa ewa_project(const float mx, const float my, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// SH rows at M > 1 (the degree-3 stress configuration: 192 B per Gaussian).  A thread reading or writing
+// its own [M][3] row straight from global memory touches 64 different 128-byte lines per wave
+// instruction and the 48 KB a workgroup covers does not survive in the vector L1.  So the workgroup moves its
+// 256 consecutive rows as ONE contiguous block with 16-byte accesses, through LDS with an odd row stride
+// (3M | 1 words: per-thread row walks are then bank-conflict free), and the arithmetic reads / writes LDS.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sh_row_stride(int C) { return C | 1; }
+
+__device__ __forceinline__ void rows_to_lds(float* lds, const float* __restrict__ src, const int nrows, const int C) {
+  const int n = nrows * C, S = sh_row_stride(C);
+  if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {  // block-uniform
+    const int C4 = C >> 2, n4 = n >> 2;
+    const int dr = PRE_BLOCK / C4, dc = PRE_BLOCK - dr * C4;
+    int r = (int)threadIdx.x / C4, c4 = (int)threadIdx.x - r * C4;
+    for (int j = threadIdx.x; j < n4; j += PRE_BLOCK) {
+      const float4 v = reinterpret_cast<const float4*>(src)[j];
+      float* d = lds + r * S + 4 * c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+      r += dr; c4 += dc;
+      if (c4 >= C4) { c4 -= C4; r++; }
+    }
+  } else {
+    const int dr = PRE_BLOCK / C, dc = PRE_BLOCK - dr * C;
+    int r = (int)threadIdx.x / C, c = (int)threadIdx.x - r * C;
+    for (int e = threadIdx.x; e < n; e += PRE_BLOCK) {
+      lds[r * S + c] = src[e];
+      r += dr; c += dc;
+      if (c >= C) { c -= C; r++; }
+    }
+  }
+}
+
+__device__ __forceinline__ void lds_to_rows(float* __restrict__ dst, const float* lds, const int nrows, const int C) {
+  const int n = nrows * C, S = sh_row_stride(C);
+  if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15u) == 0) {
+    const int C4 = C >> 2, n4 = n >> 2;
+    const int dr = PRE_BLOCK / C4, dc = PRE_BLOCK - dr * C4;
+    int r = (int)threadIdx.x / C4, c4 = (int)threadIdx.x - r * C4;
+    for (int j = threadIdx.x; j < n4; j += PRE_BLOCK) {
+      const float* d = lds + r * S + 4 * c4;
+      reinterpret_cast<float4*>(dst)[j] = make_float4(d[0], d[1], d[2], d[3]);
+      r += dr; c4 += dc;
+      if (c4 >= C4) { c4 -= C4; r++; }
+    }
+  } else {
+    const int dr = PRE_BLOCK / C, dc = PRE_BLOCK - dr * C;
+    int r = (int)threadIdx.x / C, c = (int)threadIdx.x - r * C;
+    for (int e = threadIdx.x; e < n; e += PRE_BLOCK) {
+      dst[e] = lds[r * S + c];
+      r += dr; c += dc;
+      if (c >= C) { c -= C; r++; }
+    }
+  }
+}
+
+// bytes of dynamic LDS the staged variants need; 0 = do not stage (M == 1, or rows too long for 64 KB)
+static inline size_t sh_stage_bytes(int M) {
+  if (M <= 1) return 0;
+  const size_t b = (size_t)PRE_BLOCK * (size_t)((3 * M) | 1) * sizeof(float);
+  return b <= 64 * 1024 ? b : 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // F1.  One thread per Gaussian.  Replaces preprocessCUDA (reference forward.cu:179-286).
 // ------------------------------------------------------------------------------------------------
+template <bool STAGED>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     const FrameParams fp, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
@@ -142,9 +206,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     const uint32_t ticket) {
   // A workgroup walks PRE_SUB consecutive blocks of 256 Gaussians: 4x fewer workgroups means 4x fewer
   // same-address atomics for the instance count below (they retire one at a time, ~5 ns each).
+  extern __shared__ float sh_rows[];  // STAGED: the sub-block's SH rows (rows_to_lds)
   uint32_t tiles_wg = 0;
   for (int sub = 0; sub < PRE_SUB; sub++) {
   const int idx = (blockIdx.x * PRE_SUB + sub) * PRE_BLOCK + threadIdx.x;
+  if (STAGED) {
+    const int row0 = (blockIdx.x * PRE_SUB + sub) * PRE_BLOCK;
+    if (sub) __syncthreads();  // the previous sub-block's rows have been read
+    if (row0 < fp.P) rows_to_lds(sh_rows, shs + (size_t)row0 * fp.M * 3, min(PRE_BLOCK, fp.P - row0), fp.M * 3);
+    __syncthreads();
+  }
   uint32_t tiles = 0, rect_packed = 0, dkey = 0xFFFFFFFFu;
   int radius = 0;
   if (idx < fp.P) {
@@ -198,7 +269,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
             const float d0 = mx - campos[0], d1 = my - campos[1], d2 = mz - campos[2];
             const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
             const float x = d0 / len, y = d1 / len, z = d2 / len;
-            const float* sh = shs + (size_t)idx * fp.M * 3;
+            const float* sh = STAGED ? sh_rows + threadIdx.x * sh_row_stride(fp.M * 3) : shs + (size_t)idx * fp.M * 3;
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
               float res = SH0 * sh[ch];
@@ -762,17 +833,20 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
 // order, which makes the whole backward bitwise reproducible.
 // Every output element of Gaussian idx is written (zeros when radii <= 0).
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
-    const FrameParams fp, GeomState g, const int* __restrict__ radii, const float* __restrict__ means3D, const float* __restrict__ scales,
+// `row`: null = the Gaussian's SH row is read from shs and its gradient row written to dL_dsh directly (M == 1);
+// else the LDS row that holds the SH coefficients on entry and the gradient on exit (staged variant, M > 1).
+__device__ __forceinline__ void gaussian_backward_one(
+    const int idx, float* row,
+    const FrameParams& fp, GeomState& g, const int* __restrict__ radii, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ cov3D_used,
     const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos,
     const int colors_are_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
     float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
     float* __restrict__ dL_drot) {
-  const int idx = blockIdx.x * PRE_BLOCK + threadIdx.x;
-  if (idx >= fp.P) return;
   const bool vis = radii[idx] > 0;
+  const float* sh = row ? row : shs + (size_t)idx * fp.M * 3;
+  float* gs = row ? row : dL_dsh + (size_t)idx * fp.M * 3;
   // ---- gather-sum of the instance records ----
   float gcol0 = 0, gcol1 = 0, gcol2 = 0, gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
   if (idx == 0) g.total[2] = 0u;  // the touched list has been consumed (k_gather_records ran before this kernel)
@@ -793,7 +867,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
     dL_dmean3D[3 * idx] = 0.f; dL_dmean3D[3 * idx + 1] = 0.f; dL_dmean3D[3 * idx + 2] = 0.f;
 #pragma unroll
     for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = 0.f;
-    for (int k = 0; k < 3 * M; k++) dL_dsh[(size_t)idx * M * 3 + k] = 0.f;
+    for (int k = 0; k < 3 * M; k++) gs[k] = 0.f;
     dL_dscale[3 * idx] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f;
     dL_drot[4 * idx] = 0.f; dL_drot[4 * idx + 1] = 0.f; dL_drot[4 * idx + 2] = 0.f; dL_drot[4 * idx + 3] = 0.f;
     return;
@@ -863,22 +937,25 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
     const float q0 = mx - campos[0], q1 = my - campos[1], q2 = mz - campos[2];
     const float len = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
     const float x = q0 / len, y = q1 / len, z = q2 / len;
-    const float* sh = shs + (size_t)idx * M * 3;
-    float* gs = dL_dsh + (size_t)idx * M * 3;
     float ddx = 0, ddy = 0, ddz = 0;  // dL_ddir
     const int D = fp.D;
+    const int used = (D + 1) * (D + 1);
 #pragma unroll
     for (int ch = 0; ch < 3; ch++) {
       const float gch = gr[ch];
+      // this channel's coefficients, read before its gradients are written (gs may be the same LDS row)
+      float c_[16];
+#pragma unroll
+      for (int k = 1; k < 16; k++) c_[k] = k < used ? sh[3 * k + ch] : 0.f;
       float dx_ = 0, dy_ = 0, dz_ = 0;  // dRGB/d{x,y,z} for this channel
       gs[ch] = SH0 * gch;
       if (D > 0) {
         gs[3 + ch] = (-SH1 * y) * gch;
         gs[6 + ch] = (SH1 * z) * gch;
         gs[9 + ch] = (-SH1 * x) * gch;
-        dx_ = -SH1 * sh[9 + ch];
-        dy_ = -SH1 * sh[3 + ch];
-        dz_ = SH1 * sh[6 + ch];
+        dx_ = -SH1 * c_[3];
+        dy_ = -SH1 * c_[1];
+        dz_ = SH1 * c_[2];
         if (D > 1) {
           const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
           gs[12 + ch] = (SH2c[0] * xy) * gch;
@@ -886,11 +963,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
           gs[18 + ch] = (SH2c[2] * (2.f * zz - xx - yy)) * gch;
           gs[21 + ch] = (SH2c[3] * xz) * gch;
           gs[24 + ch] = (SH2c[4] * (xx - yy)) * gch;
-          dx_ += SH2c[0] * y * sh[12 + ch] + SH2c[2] * 2.f * -x * sh[18 + ch] + SH2c[3] * z * sh[21 + ch] +
-                 SH2c[4] * 2.f * x * sh[24 + ch];
-          dy_ += SH2c[0] * x * sh[12 + ch] + SH2c[1] * z * sh[15 + ch] + SH2c[2] * 2.f * -y * sh[18 + ch] +
-                 SH2c[4] * 2.f * -y * sh[24 + ch];
-          dz_ += SH2c[1] * y * sh[15 + ch] + SH2c[2] * 2.f * 2.f * z * sh[18 + ch] + SH2c[3] * x * sh[21 + ch];
+          dx_ += SH2c[0] * y * c_[4] + SH2c[2] * 2.f * -x * c_[6] + SH2c[3] * z * c_[7] +
+                 SH2c[4] * 2.f * x * c_[8];
+          dy_ += SH2c[0] * x * c_[4] + SH2c[1] * z * c_[5] + SH2c[2] * 2.f * -y * c_[6] +
+                 SH2c[4] * 2.f * -y * c_[8];
+          dz_ += SH2c[1] * y * c_[5] + SH2c[2] * 2.f * 2.f * z * c_[6] + SH2c[3] * x * c_[7];
           if (D > 2) {
             gs[27 + ch] = (SH3c[0] * y * (3.f * xx - yy)) * gch;
             gs[30 + ch] = (SH3c[1] * xy * z) * gch;
@@ -899,17 +976,17 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
             gs[39 + ch] = (SH3c[4] * x * (4.f * zz - xx - yy)) * gch;
             gs[42 + ch] = (SH3c[5] * z * (xx - yy)) * gch;
             gs[45 + ch] = (SH3c[6] * x * (xx - 3.f * yy)) * gch;
-            dx_ += (SH3c[0] * sh[27 + ch] * 3.f * 2.f * xy + SH3c[1] * sh[30 + ch] * yz +
-                    SH3c[2] * sh[33 + ch] * -2.f * xy + SH3c[3] * sh[36 + ch] * -3.f * 2.f * xz +
-                    SH3c[4] * sh[39 + ch] * (-3.f * xx + 4.f * zz - yy) + SH3c[5] * sh[42 + ch] * 2.f * xz +
-                    SH3c[6] * sh[45 + ch] * 3.f * (xx - yy));
-            dy_ += (SH3c[0] * sh[27 + ch] * 3.f * (xx - yy) + SH3c[1] * sh[30 + ch] * xz +
-                    SH3c[2] * sh[33 + ch] * (-3.f * yy + 4.f * zz - xx) + SH3c[3] * sh[36 + ch] * -3.f * 2.f * yz +
-                    SH3c[4] * sh[39 + ch] * -2.f * xy + SH3c[5] * sh[42 + ch] * -2.f * yz +
-                    SH3c[6] * sh[45 + ch] * -3.f * 2.f * xy);
-            dz_ += (SH3c[1] * sh[30 + ch] * xy + SH3c[2] * sh[33 + ch] * 4.f * 2.f * yz +
-                    SH3c[3] * sh[36 + ch] * 3.f * (2.f * zz - xx - yy) + SH3c[4] * sh[39 + ch] * 4.f * 2.f * xz +
-                    SH3c[5] * sh[42 + ch] * (xx - yy));
+            dx_ += (SH3c[0] * c_[9] * 3.f * 2.f * xy + SH3c[1] * c_[10] * yz +
+                    SH3c[2] * c_[11] * -2.f * xy + SH3c[3] * c_[12] * -3.f * 2.f * xz +
+                    SH3c[4] * c_[13] * (-3.f * xx + 4.f * zz - yy) + SH3c[5] * c_[14] * 2.f * xz +
+                    SH3c[6] * c_[15] * 3.f * (xx - yy));
+            dy_ += (SH3c[0] * c_[9] * 3.f * (xx - yy) + SH3c[1] * c_[10] * xz +
+                    SH3c[2] * c_[11] * (-3.f * yy + 4.f * zz - xx) + SH3c[3] * c_[12] * -3.f * 2.f * yz +
+                    SH3c[4] * c_[13] * -2.f * xy + SH3c[5] * c_[14] * -2.f * yz +
+                    SH3c[6] * c_[15] * -3.f * 2.f * xy);
+            dz_ += (SH3c[1] * c_[10] * xy + SH3c[2] * c_[11] * 4.f * 2.f * yz +
+                    SH3c[3] * c_[12] * 3.f * (2.f * zz - xx - yy) + SH3c[4] * c_[13] * 4.f * 2.f * xz +
+                    SH3c[5] * c_[14] * (xx - yy));
           }
         }
       }
@@ -918,7 +995,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
       ddz += dz_ * gch;
     }
     // coefficients beyond the active degree get zero gradient
-    const int used = (D + 1) * (D + 1);
     for (int k = used * 3; k < M * 3; k++) gs[k] = 0.f;
     const float sum2 = q0 * q0 + q1 * q1 + q2 * q2;
     const float inv32 = 1.0f / sqrtf(sum2 * sum2 * sum2);
@@ -926,7 +1002,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
     dm1 += (-q0 * q1 * ddx + (sum2 - q1 * q1) * ddy - q2 * q1 * ddz) * inv32;
     dm2 += (-q0 * q2 * ddx - q1 * q2 * ddy + (sum2 - q2 * q2) * ddz) * inv32;
   } else {
-    for (int k = 0; k < M * 3; k++) dL_dsh[(size_t)idx * M * 3 + k] = 0.f;
+    for (int k = 0; k < M * 3; k++) gs[k] = 0.f;
   }
   dL_dmean3D[3 * idx] = dm0; dL_dmean3D[3 * idx + 1] = dm1; dL_dmean3D[3 * idx + 2] = dm2;
   // ---- covariance -> scale / rotation (backward.cu:279-366) ----
@@ -978,6 +1054,32 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
   }
 }
 
+template <bool STAGED>
+__global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
+    const FrameParams fp, GeomState g, const int* __restrict__ radii, const float* __restrict__ means3D, const float* __restrict__ scales,
+    const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ cov3D_used,
+    const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos,
+    const int colors_are_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
+    float* __restrict__ dL_dmean3D,
+    float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
+    float* __restrict__ dL_drot) {
+  extern __shared__ float sh_rows[];  // STAGED: SH rows in, dL_dsh rows out (rows_to_lds / lds_to_rows)
+  const int row0 = blockIdx.x * PRE_BLOCK, idx = row0 + threadIdx.x;
+  const int C = fp.M * 3, nrows = min(PRE_BLOCK, fp.P - row0);
+  if (STAGED) {
+    rows_to_lds(sh_rows, shs + (size_t)row0 * C, nrows, C);
+    __syncthreads();
+  }
+  if (idx < fp.P)
+    gaussian_backward_one(idx, STAGED ? sh_rows + threadIdx.x * sh_row_stride(C) : nullptr, fp, g, radii, means3D, scales,
+                          rotations, shs, cov3D_used, V, Pm, campos, colors_are_precomp, dL_dmean2D, dL_dconic,
+                          dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+  if (STAGED) {
+    __syncthreads();
+    lds_to_rows(dL_dsh + (size_t)row0 * C, sh_rows, nrows, C);
+  }
+}
+
 // V1.  Replaces checkFrustum / in_frustum (reference rasterizer_impl.cu:52-60, auxiliary.h:120-144).
 __global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float* __restrict__ means3D,
                                                             const float* __restrict__ V,
@@ -996,8 +1098,14 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
                              unsigned long long* publish, uint32_t ticket, hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps_k_preprocess(K_PREPROCESS, s);
-  hipLaunchKernelGGL(k_preprocess, dim3((nb + PRE_SUB - 1) / PRE_SUB), dim3(PRE_BLOCK), 0, s, fp, means3D, scales, rotations, opacities, shs,
-                     cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket);
+  const dim3 grid((nb + PRE_SUB - 1) / PRE_SUB);
+  const size_t stage = (shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0;  // M > 1: SH rows go through LDS
+  if (stage)
+    hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(PRE_BLOCK), stage, s, fp, means3D, scales, rotations, opacities,
+                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket);
+  else
+    hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(PRE_BLOCK), 0, s, fp, means3D, scales, rotations, opacities,
+                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket);
   return hipGetLastError();
 }
 
@@ -1059,7 +1167,10 @@ hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningStat
   }
   {
     ProfScope ps(K_GATHER_RECORDS, s);
-    const int grid = nb < 4096 ? nb : 4096;  // grid-stride over the touched list, one Gaussian per wave
+    // grid-stride over the touched list, one Gaussian per wave: up to P waves' worth of workgroups (the list
+    // length is only known on the device), capped where the chip is full several times over
+    const int want = (fp.P + PRE_BLOCK / 64 - 1) / (PRE_BLOCK / 64);
+    const int grid = want < 4096 ? want : 4096;
     hipLaunchKernelGGL(k_gather_records, dim3(grid), dim3(PRE_BLOCK), 0, s, g, b.grad_inst, b.inst_flag, dL_dmean2D,
                        dL_dconic, dL_dopacity, dL_dcolor);
   }
@@ -1074,9 +1185,15 @@ hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningS
                                     float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps_k_gaussian_bwd(K_GAUSSIAN_BWD, s);
-  hipLaunchKernelGGL(k_gaussian_backward, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, radii,
-                     means3D, scales, rotations, shs, cov3D_used, view, proj, campos, colors_precomp ? 1 : 0,
-                     dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+  const size_t stage = (shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0;  // M > 1: SH / dL_dsh rows go through LDS
+  if (stage)
+    hipLaunchKernelGGL(k_gaussian_backward<true>, dim3(nb), dim3(PRE_BLOCK), stage, s, fp, g, radii,
+                       means3D, scales, rotations, shs, cov3D_used, view, proj, campos, 0,
+                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+  else
+    hipLaunchKernelGGL(k_gaussian_backward<false>, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, radii,
+                       means3D, scales, rotations, shs, cov3D_used, view, proj, campos, colors_precomp ? 1 : 0,
+                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
   return hipGetLastError();
 }
 

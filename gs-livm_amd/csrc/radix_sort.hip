@@ -245,15 +245,10 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
 // Depth sort of the P (depth bits, Gaussian id) pairs: 32-bit keys, four 8-bit passes, FIVE launches
 // (histograms of all digits, then one look-back scatter per pass).  Pairs start in (keysA, valsA) and end
 // there.  sc.words (ghist | tickets | status) must be zero on entry: k_preprocess clears it.
-hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
-                             int n, hipStream_t s) {
-  if (n <= 0) return hipSuccess;
-  const int ntiles = (n + SORT_TILE - 1) / SORT_TILE;
-  {
-    ProfScope ps(K_DSORT_HIST, s);
-    hipLaunchKernelGGL(k_sort_hist_all, dim3(ntiles < 256 ? ntiles : 256), dim3(256), 0, s, keysA, n, sc.ghist());
-  }
-  const bool arank = lds_atomic_rank_ok(s);
+template <int TILE>
+static void depth_sort_passes(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
+                              int n, bool arank, hipStream_t s) {
+  const int ntiles = (n + TILE - 1) / TILE;
   bool inA = true;
   for (int p = 0; p < 4; p++) {
     ProfScope ps(K_DSORT_SCATTER, s);
@@ -262,15 +257,30 @@ hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
     uint32_t* kout = inA ? keysB : keysA;
     uint32_t* vout = inA ? valsB : valsA;
     if (arank)
-      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true, 4, SORT_TILE>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true, 4, TILE>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
                          8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     else
-      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false, 4, SORT_TILE>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout,
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false, 4, TILE>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout,
                          n, 8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     inA = !inA;
   }
+}
+
+hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
+                             int n, hipStream_t s) {
+  if (n <= 0) return hipSuccess;
+  {
+    const int nwg = (n + SORT_TILE - 1) / SORT_TILE;
+    ProfScope ps(K_DSORT_HIST, s);
+    hipLaunchKernelGGL(k_sort_hist_all, dim3(nwg < 256 ? nwg : 256), dim3(256), 0, s, keysA, n, sc.ghist());
+  }
+  const bool arank = lds_atomic_rank_ok(s);
+  if (depth_sort_tile((size_t)n) == (size_t)SORT_TILE_SMALL)
+    depth_sort_passes<SORT_TILE_SMALL>(keysA, valsA, keysB, valsB, sc, n, arank, s);
+  else
+    depth_sort_passes<SORT_TILE>(keysA, valsA, keysB, valsB, sc, n, arank, s);
   return hipGetLastError();
 }
 

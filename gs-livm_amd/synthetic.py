@@ -103,5 +103,8 @@ CONFIGS = {
     "C1": (10_000, 640, 480, 1),
     "C2": (500_000, 1280, 720, 2),
     "C3": (2_000_000, 1920, 1080, 3),
+    # not a BASELINE config: the SHAPE of C5 (HKU-Campus replay renders 640x512 at SH degree 0 over a map that grows
+    # to 1e5..1e6 Gaussians) on the synthetic scene -- the small-frame, host-bound regime
+    "C5shape": (300_000, 640, 512, 5),
 }
 C4_YAWS_DEG = (-21.0, -15.0, -9.0, -3.0, 3.0, 9.0, 15.0, 21.0)

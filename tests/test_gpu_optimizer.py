@@ -76,11 +76,12 @@ def test_fused_adam_matches_torch_adam(gpu_device):
             torch.testing.assert_close(mine.state[b][key], r, rtol=5e-5, atol=1e-5 * float(r.abs().max()))
 
 
-def test_one_optimiser_iteration_fused_vs_torch_ops(gpu_device):
+@pytest.mark.parametrize("P,D", [(3000, 1), (3001, 2), (1500, 3)])  # M = 4 / 9 / 16; odd last workgroup at M = 9
+def test_one_optimiser_iteration_fused_vs_torch_ops(P, D, gpu_device):
     """activations -> rasterizer -> backward -> Adam: the fused path and the reference's separate Torch ops end
     in the same parameters."""
     dev = gpu_device
-    P, W, H, D = 3000, 200, 120, 1
+    W, H = 200, 120
     r = _raw(P, D, dev, seed=9)
     cam = S.make_camera(W, H)
     st = G.GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], torch.ones(3, device=dev), 1.0,

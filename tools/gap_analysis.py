@@ -8,7 +8,9 @@ def short(n):
     return n.split("::")[-1]
 names = [short(r["Kernel_Name"]) for r in rows]
 # a step starts at k_activate (or k_preprocess when the optimiser is off); take the last complete steps
-starts = [i for i, n in enumerate(names) if n == "k_activate"] or [i for i, n in enumerate(names) if n == "k_preprocess"]
+starts = [i for i, n in enumerate(names) if n == "k_activate"]
+if len(starts) < 3:  # one-kernel optimiser tail: k_activate only runs once, before the first step
+    starts = [i for i, n in enumerate(names) if n == "k_preprocess"]
 nsteps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 starts = starts[-(nsteps + 1):]
 agg = {}
