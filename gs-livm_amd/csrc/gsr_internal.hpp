@@ -60,7 +60,6 @@ struct SortScratch {  // scratch of one radix sort over n (u32 key, u32 value) p
 // Scratch of the single-launch (decoupled look-back) kernels -- the depth sort (radix_sort.hip: all-digit
 // histograms, tile tickets, per-(pass, tile, digit) status words) and the slot-offset scan (k_scan_offsets:
 // ticket + one 64-bit status word per 4096 Gaussians) -- in ONE array that k_preprocess clears as a side job.
-constexpr int PRE_SUB = 4;      // 256-Gaussian blocks walked by one k_preprocess workgroup
 constexpr int SCAN_ITEMS = 16;                    // consecutive Gaussians per thread in k_scan_offsets
 constexpr int SCAN_TILE = PRE_BLOCK * SCAN_ITEMS;  // 4096
 // Workgroup tile of the depth sort's scatter passes: maps of up to 128 k Gaussians get 1024-pair tiles so a pass

@@ -103,15 +103,19 @@ __global__ __launch_bounds__(256) void k_loss_forward(const int C, const int H, 
   }
 }
 
-__global__ __launch_bounds__(256) void k_loss_finalize(const float* __restrict__ partials, const int nblocks,
-                                                       const float inv_n, const float lambda,
-                                                       float* __restrict__ out3) {
-  __shared__ double r1[256], r2[256];
+__global__ __launch_bounds__(1024) void k_loss_finalize(const float* __restrict__ partials, const int nblocks,
+                                                        const float inv_n, const float lambda,
+                                                        float* __restrict__ out3) {
+  // one workgroup, fixed association order (thread-strided partial sums in f64, then a tree): deterministic
+  __shared__ double r1[1024], r2[1024];
   double a = 0.0, b = 0.0;
-  for (int i = threadIdx.x; i < nblocks; i += 256) { a += partials[2 * i]; b += partials[2 * i + 1]; }
+  for (int i = threadIdx.x; i < nblocks; i += 1024) {
+    const float2 v = reinterpret_cast<const float2*>(partials)[i];
+    a += v.x; b += v.y;
+  }
   r1[threadIdx.x] = a; r2[threadIdx.x] = b;
   __syncthreads();
-  for (int o = 128; o > 0; o >>= 1) {
+  for (int o = 512; o > 0; o >>= 1) {
     if ((int)threadIdx.x < o) { r1[threadIdx.x] += r1[threadIdx.x + o]; r2[threadIdx.x] += r2[threadIdx.x + o]; }
     __syncthreads();
   }
@@ -199,7 +203,7 @@ hipError_t launch_photometric_loss(int C, int H, int W, const float* img, const 
   }
   {
     ProfScope ps(K_LOSS_FINALIZE, s);
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(256), 0, s, partials, nblocks, inv_n, lambda, loss_out3);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, partials, nblocks, inv_n, lambda, loss_out3);
   }
   if (dL_dimg) {
     ProfScope ps(K_LOSS_BWD, s);

@@ -204,29 +204,56 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     int* __restrict__ radii_out, unsigned long long* __restrict__ done_word,
     unsigned long long* __restrict__ publish,
     const uint32_t ticket) {
-  // A workgroup walks PRE_SUB consecutive blocks of 256 Gaussians: 4x fewer workgroups means 4x fewer
-  // same-address atomics for the instance count below (they retire one at a time, ~5 ns each).
+  // Persistent-style grid: the launcher sizes the grid to ONE resident round of workgroups (preprocess_grid) and
+  // workgroup b walks the 256-Gaussian blocks b, b + grid, b + 2 grid, ...: no second, mostly empty round of
+  // workgroups at the end, every workgroup does the same number of blocks (+-1), and the instance count below
+  // costs one same-address atomic per workgroup (they retire one at a time, ~5 ns each) instead of one per block.
   extern __shared__ float sh_rows[];  // STAGED: the sub-block's SH rows (rows_to_lds)
+  // Every input of a Gaussian is fetched up front and unconditionally (one round trip instead of one per cull
+  // stage: means -> scales -> rotation -> opacity / colour), and the NEXT sub-block's inputs are requested before
+  // this one is worked on, so the arithmetic of a wave overlaps its own loads.
+  struct In { float mx, my, mz, s0, s1, s2, op, dc0, dc1, dc2; float4 q; };
+  const bool dc_direct = !STAGED && shs && !colors_precomp;  // first SH coefficient read with the other inputs
+  auto fetch = [&](const int i) {
+    In v;
+    v.mx = v.my = v.mz = v.s0 = v.s1 = v.s2 = v.op = v.dc0 = v.dc1 = v.dc2 = 0.f;
+    v.q = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i < fp.P) {
+      v.mx = means3D[3 * i]; v.my = means3D[3 * i + 1]; v.mz = means3D[3 * i + 2];
+      if (scales) { v.s0 = scales[3 * i]; v.s1 = scales[3 * i + 1]; v.s2 = scales[3 * i + 2]; }
+      if (!cov3D_precomp) v.q = reinterpret_cast<const float4*>(rotations)[i];
+      v.op = opacities[i];
+      if (dc_direct) {
+        const float* r = shs + (size_t)i * fp.M * 3;
+        v.dc0 = r[0]; v.dc1 = r[1]; v.dc2 = r[2];
+      }
+    }
+    return v;
+  };
   uint32_t tiles_wg = 0;
-  for (int sub = 0; sub < PRE_SUB; sub++) {
-  const int idx = (blockIdx.x * PRE_SUB + sub) * PRE_BLOCK + threadIdx.x;
+  const int nblk = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
+  In nxt = fetch(blockIdx.x * PRE_BLOCK + threadIdx.x);
+  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
+  const int idx = blk * PRE_BLOCK + threadIdx.x;
+  const In in = nxt;
+  if (blk + (int)gridDim.x < nblk) nxt = fetch(idx + (int)gridDim.x * PRE_BLOCK);
   if (STAGED) {
-    const int row0 = (blockIdx.x * PRE_SUB + sub) * PRE_BLOCK;
-    if (sub) __syncthreads();  // the previous sub-block's rows have been read
+    const int row0 = blk * PRE_BLOCK;
+    if (blk != (int)blockIdx.x) __syncthreads();  // the previous block's rows have been read
     if (row0 < fp.P) rows_to_lds(sh_rows, shs + (size_t)row0 * fp.M * 3, min(PRE_BLOCK, fp.P - row0), fp.M * 3);
     __syncthreads();
   }
   uint32_t tiles = 0, rect_packed = 0, dkey = 0xFFFFFFFFu;
   int radius = 0;
   if (idx < fp.P) {
-    const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+    const float mx = in.mx, my = in.my, mz = in.mz;
     const float pvz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
     bool alive = !(pvz <= 0.2f);  // near cull only (forward.cu:221-225)
     float s0 = 0, s1 = 0, s2 = 0;
     if (alive && scales) {  // scale cull (forward.cu:19-25)
-      s0 = fp.scale_modifier * scales[3 * idx];
-      s1 = fp.scale_modifier * scales[3 * idx + 1];
-      s2 = fp.scale_modifier * scales[3 * idx + 2];
+      s0 = fp.scale_modifier * in.s0;
+      s1 = fp.scale_modifier * in.s1;
+      s2 = fp.scale_modifier * in.s2;
       alive = !(s0 > 0.3f || s1 > 0.3f || s2 > 0.3f);
     }
     if (alive) {
@@ -240,7 +267,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
 #pragma unroll
         for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * idx + k];
       } else {
-        cov3d_from_scale_rot(s0, s1, s2, reinterpret_cast<const float4*>(rotations)[idx], c6);
+        cov3d_from_scale_rot(s0, s1, s2, in.q, c6);
 #pragma unroll
         for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)idx + k] = c6[k];
       }
@@ -270,9 +297,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
             const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
             const float x = d0 / len, y = d1 / len, z = d2 / len;
             const float* sh = STAGED ? sh_rows + threadIdx.x * sh_row_stride(fp.M * 3) : shs + (size_t)idx * fp.M * 3;
+            const float dc[3] = {dc_direct ? in.dc0 : sh[0], dc_direct ? in.dc1 : sh[1], dc_direct ? in.dc2 : sh[2]};
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
-              float res = SH0 * sh[ch];
+              float res = SH0 * dc[ch];
               if (fp.D > 0) {
                 res = res - SH1 * y * sh[3 + ch] + SH1 * z * sh[6 + ch] - SH1 * x * sh[9 + ch];
                 if (fp.D > 1) {
@@ -294,7 +322,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
               rgb[ch] = fmax_(res, 0.0f);
             }
           }
-          const float op = opacities[idx];
+          const float op = in.op;
           // Exact-conservative footprint: a pixel can only receive alpha = min(.99, op*exp(power)) >= 1/255
           // if -power <= ln(255*op); the axis-aligned box of that ellipse (plus slack for rounding in
           // the blend kernels) bounds every contributing pixel.  op < 1/255 never contributes.
@@ -1098,8 +1126,11 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
                              unsigned long long* publish, uint32_t ticket, hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps_k_preprocess(K_PREPROCESS, s);
-  const dim3 grid((nb + PRE_SUB - 1) / PRE_SUB);
   const size_t stage = (shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0;  // M > 1: SH rows go through LDS
+  // one resident round: 8 workgroups of 4 waves per CU (3 when 50 KB of LDS each hold SH rows) x 256 CUs, the
+  // blocks spread evenly over them (C3 measured: 6 per CU 101 us, 8 per CU 80 us, 16 per CU 93 us)
+  const int max_wg = (stage ? 3 : 8) * 256, rounds = (nb + max_wg - 1) / max_wg;
+  const dim3 grid(rounds ? (nb + rounds - 1) / rounds : 1);
   if (stage)
     hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(PRE_BLOCK), stage, s, fp, means3D, scales, rotations, opacities,
                        shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket);
