@@ -192,7 +192,9 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   // the first kernel retires -- the per-Gaussian depth sort, which does not depend on R, is already enqueued
   // behind it and runs while the host sizes and allocates the binning blob.
   // A host thread is inside this wait for one forward at a time, so the mailbox and the kernel's
-  // "workgroups done" counter (which its last workgroup resets) can be per-thread singletons.
+  // "workgroups done" counter (which its last workgroup resets) can be per-thread singletons.  (They, and the
+  // digit-histogram buffers below, assume that the forwards of one host thread on one device are ordered on the
+  // device -- one stream, as the reference's default-stream use -- not issued concurrently on several streams.)
   static thread_local unsigned long long* mailbox = nullptr;  // host pointer
   static thread_local unsigned long long* mailbox_dev = nullptr;
   static thread_local unsigned long long* done_counter = nullptr;  // device: (workgroups done << 40 | sum)
@@ -205,8 +207,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     void* d = nullptr;
     void* c = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipMalloc(&c, 64) != hipSuccess ||
-        hipMemset(c, 0, 64) != hipSuccess)
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipMalloc(&c, 64 + 2 * 4096) != hipSuccess ||
+        hipMemset(c, 0, 64 + 2 * 4096) != hipSuccess)
       return fail(GSR_ERR_HIP, "cannot allocate the host-mapped mailbox: %s", hipGetErrorString(hipGetLastError()));
     mailbox = static_cast<unsigned long long*>(h);  // (a previous device's 128 bytes stay allocated: switching is rare)
     mailbox_dev = static_cast<unsigned long long*>(d);
@@ -217,9 +219,19 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     (void)hipDeviceSynchronize();  // the counter is zero before any stream uses it
   }
   ticket = ticket == 0xFFFFFFFFu ? 1u : ticket + 1u;  // never 0: the mailbox starts at ticket 0
+  // Digit histograms of the depth sort, counted by k_preprocess: two library-owned [4][256] buffers behind the
+  // counter, used alternately -- a forward counts into one (zero on entry) and clears the other for the next
+  // forward of this thread, so a call that ends early never leaves a dirty buffer in the way.
+  // GSR_DEPTH_HIST_PASS=1 restores the sort's own histogram pass (k_sort_hist_all).
+  static const bool own_hist_pass = getenv("GSR_DEPTH_HIST_PASS") != nullptr;
+  uint32_t* const ghist2 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(done_counter) + 64);
+  static thread_local uint32_t hist_flip = 0;  // (not the ticket: its wrap-around skips 0 and would repeat a parity)
+  hist_flip ^= 1u;
+  uint32_t* const ghist_acc = own_hist_pass ? nullptr : ghist2 + 1024 * hist_flip;
+  uint32_t* const ghist_clear = own_hist_pass ? nullptr : ghist2 + 1024 * (hist_flip ^ 1u);
   STAGE(launch_preprocess(fp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
-                          projmatrix, cam_pos, g, radii, done_counter, mailbox_dev, ticket, stream));
-  STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, stream));
+                          projmatrix, cam_pos, g, radii, done_counter, mailbox_dev, ticket, ghist_acc, ghist_clear, stream));
+  STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, ghist_acc, stream));
   if (debug) STAGE(launch_point_offsets(fp, g, stream));  // the reference's array, for the views only
   uint32_t R_host = 0;
   const std::chrono::steady_clock::time_point t_enqueued = std::chrono::steady_clock::now();

@@ -206,7 +206,8 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
                              const float* opacities, const float* shs, const float* cov3D_precomp,
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,
                              GeomState g, int* radii_out, unsigned long long* done_word,
-                             unsigned long long* publish, uint32_t ticket, hipStream_t s);
+                             unsigned long long* publish, uint32_t ticket, uint32_t* ghist_acc, uint32_t* ghist_clear,
+                             hipStream_t s);
 hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
 hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint2* ranges,
                                uint32_t* counts0, hipStream_t s);
@@ -231,7 +232,7 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
                              int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
                              bool first_hist_done, const EmitFusion* fused_first_pass, hipStream_t s);
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
-                             int n, hipStream_t s);
+                             int n, const uint32_t* ghist, hipStream_t s);
 hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, bool key16, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, hipStream_t s);

@@ -203,12 +203,24 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos, GeomState g,
     int* __restrict__ radii_out, unsigned long long* __restrict__ done_word,
     unsigned long long* __restrict__ publish,
-    const uint32_t ticket) {
+    const uint32_t ticket, uint32_t* __restrict__ ghist_acc, uint32_t* __restrict__ ghist_clear) {
   // Persistent-style grid: the launcher sizes the grid to ONE resident round of workgroups (preprocess_grid) and
   // workgroup b walks the 256-Gaussian blocks b, b + grid, b + 2 grid, ...: no second, mostly empty round of
   // workgroups at the end, every workgroup does the same number of blocks (+-1), and the instance count below
   // costs one same-address atomic per workgroup (they retire one at a time, ~5 ns each) instead of one per block.
   extern __shared__ float sh_rows[];  // STAGED: the sub-block's SH rows (rows_to_lds)
+  // The depth sort's four digit histograms are counted here, where the keys are made (LDS atomics, one flush of
+  // the non-empty bins per workgroup): the sort needs no histogram pass of its own.  ghist_acc is library-owned
+  // and zero on entry; ghist_clear is the buffer the NEXT forward will count into.
+  __shared__ uint32_t dhist[4][256];
+  if (ghist_acc) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) dhist[k][threadIdx.x] = 0u;
+    if (blockIdx.x == 0)
+#pragma unroll
+      for (int k = 0; k < 4; k++) ghist_clear[k * 256 + threadIdx.x] = 0u;
+    __syncthreads();
+  }
   // Every input of a Gaussian is fetched up front and unconditionally (one round trip instead of one per cull
   // stage: means -> scales -> rotation -> opacity / colour), and the NEXT sub-block's inputs are requested before
   // this one is worked on, so the arithmetic of a wave overlaps its own loads.
@@ -378,6 +390,20 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     g.dkeysA[idx] = dkey;
     g.order[idx] = (uint32_t)idx;
   }
+  if (ghist_acc) {
+    // Gaussians without instances all carry the key 0xFFFFFFFF: counted per wave, not per lane (one address)
+    const bool has = idx < fp.P, none = has && dkey == 0xFFFFFFFFu;
+    const uint64_t nm = __ballot(none);
+    if (has && !none) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) atomicAdd(&dhist[k][(dkey >> (8 * k)) & 255u], 1u);
+    }
+    if (nm != 0ull && (threadIdx.x & 63) == 0) {
+      const uint32_t c = (uint32_t)__popcll(nm);
+#pragma unroll
+      for (int k = 0; k < 4; k++) atomicAdd(&dhist[k][255], c);
+    }
+  }
   tiles_wg += tiles;
   }
   // side job: clear the depth sort's histograms, tickets and look-back status words
@@ -387,6 +413,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   const uint32_t ws = wave_sum_u32(tiles_wg);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
   __syncthreads();
+  if (ghist_acc) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const uint32_t c = dhist[k][threadIdx.x];
+      if (c) (void)__hip_atomic_fetch_add(ghist_acc + k * 256 + threadIdx.x, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
   // num_rendered without a scan launch and without a release fence (an agent-scope fence writes back the XCD's
   // L2: ~75 ns per workgroup when 7813 of them do it): every workgroup adds (1 << 40 | its sum) to ONE 64-bit
   // word, so the count of finished workgroups and the running total travel in the same atomic.  The workgroup
@@ -1123,7 +1156,8 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
                              const float* opacities, const float* shs, const float* cov3D_precomp,
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,
                              GeomState g, int* radii_out, unsigned long long* done_word,
-                             unsigned long long* publish, uint32_t ticket, hipStream_t s) {
+                             unsigned long long* publish, uint32_t ticket, uint32_t* ghist_acc, uint32_t* ghist_clear,
+                             hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps_k_preprocess(K_PREPROCESS, s);
   const size_t stage = (shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0;  // M > 1: SH rows go through LDS
@@ -1133,10 +1167,12 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
   const dim3 grid(rounds ? (nb + rounds - 1) / rounds : 1);
   if (stage)
     hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(PRE_BLOCK), stage, s, fp, means3D, scales, rotations, opacities,
-                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket);
+                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket,
+                       ghist_acc, ghist_clear);
   else
     hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(PRE_BLOCK), 0, s, fp, means3D, scales, rotations, opacities,
-                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket);
+                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket,
+                       ghist_acc, ghist_clear);
   return hipGetLastError();
 }
 

@@ -18,7 +18,7 @@
 //     runs instead of 64 scattered dwords per instruction.
 // Instance (tile-id) sort, R ~ 10^7 pairs, u16 keys: classic passes -- per-tile digit counts (from k_emit for
 //   the first pass, k_sort_hist after that), k_sort_scan_chunks / k_sort_scan_top, k_sort_scatter.
-// Depth sort, P ~ 10^6 pairs, u32 keys: k_sort_hist_all (all four digit histograms in one pass) and ONE launch
+// Depth sort, P ~ 10^6 pairs, u32 keys: digit histograms from the key producer (or k_sort_hist_all) and ONE launch
 //   per pass with decoupled look-back (LB): ticketed tiles, one status word per (tile, digit), counts published
 //   right after the key load.  For the 10^7-pair sort the look-back measured slower than the helper kernels
 //   (DESIGN.md "Tried and rejected"), for the 10^6-pair sort it replaces 16 launches by 5.
@@ -242,12 +242,13 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
                                    nullptr, s);
 }
 
-// Depth sort of the P (depth bits, Gaussian id) pairs: 32-bit keys, four 8-bit passes, FIVE launches
-// (histograms of all digits, then one look-back scatter per pass).  Pairs start in (keysA, valsA) and end
+// Depth sort of the P (depth bits, Gaussian id) pairs: 32-bit keys, four 8-bit passes, one look-back scatter launch
+// per pass; `ghist` = the [4][256] digit histograms if the producer of the keys counted them (k_preprocess
+// does), else null and k_sort_hist_all counts them first.  Pairs start in (keysA, valsA) and end
 // there.  sc.words (ghist | tickets | status) must be zero on entry: k_preprocess clears it.
 template <int TILE>
 static void depth_sort_passes(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
-                              int n, bool arank, hipStream_t s) {
+                              int n, bool arank, const uint32_t* ghist, hipStream_t s) {
   const int ntiles = (n + TILE - 1) / TILE;
   bool inA = true;
   for (int p = 0; p < 4; p++) {
@@ -258,29 +259,30 @@ static void depth_sort_passes(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB,
     uint32_t* vout = inA ? valsB : valsA;
     if (arank)
       hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true, 4, TILE>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
-                         8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
+                         8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, ghist + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     else
       hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false, 4, TILE>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout,
-                         n, 8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, sc.ghist() + 256 * p,
+                         n, 8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, ghist + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     inA = !inA;
   }
 }
 
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
-                             int n, hipStream_t s) {
+                             int n, const uint32_t* ghist, hipStream_t s) {
   if (n <= 0) return hipSuccess;
-  {
+  if (!ghist) {  // the producer of the keys did not count the digits: one histogram pass over them
+    ghist = sc.ghist();
     const int nwg = (n + SORT_TILE - 1) / SORT_TILE;
     ProfScope ps(K_DSORT_HIST, s);
     hipLaunchKernelGGL(k_sort_hist_all, dim3(nwg < 256 ? nwg : 256), dim3(256), 0, s, keysA, n, sc.ghist());
   }
   const bool arank = lds_atomic_rank_ok(s);
   if (depth_sort_tile((size_t)n) == (size_t)SORT_TILE_SMALL)
-    depth_sort_passes<SORT_TILE_SMALL>(keysA, valsA, keysB, valsB, sc, n, arank, s);
+    depth_sort_passes<SORT_TILE_SMALL>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, s);
   else
-    depth_sort_passes<SORT_TILE>(keysA, valsA, keysB, valsB, sc, n, arank, s);
+    depth_sort_passes<SORT_TILE>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, s);
   return hipGetLastError();
 }
 

@@ -278,10 +278,13 @@ def test_huge_image_32bit_tile_keys(gpu_device):
     assert fr.ranges.shape[0] == 257 * 257 and int(fr.ranges.max()) == fr.R
 
 
-def test_sort_fallback_without_lds_atomic_ranking(gpu_device):
+@pytest.mark.parametrize("knob", ["GSR_SORT_BALLOT_RANK", "GSR_DEPTH_HIST_PASS"])
+def test_sort_fallback_paths(knob, gpu_device):
     """The radix scatter ranks with returning LDS atomics only after a one-time probe of the hardware's conflict
-    order; GSR_SORT_BALLOT_RANK=1 forces the ballot-match variant the library falls back to.  It is chosen at the
-    first launch of a process, so the check runs in a child process: bit-exact lists against the oracle there too."""
+    order; GSR_SORT_BALLOT_RANK=1 forces the ballot-match variant the library falls back to.  GSR_DEPTH_HIST_PASS=1
+    makes the depth sort count its digits itself instead of taking the histograms k_preprocess counted.  Both are
+    read once per process, so the check runs in a child process: bit-exact lists against the oracle there too
+    (three forwards: the library-owned histogram buffers alternate between calls)."""
     import subprocess
     import sys
     code = (
@@ -293,13 +296,14 @@ def test_sort_fallback_without_lds_atomic_ranking(gpu_device):
         "from helpers import hip_forward\n"
         "sc = S.make_scene(40000, 500, 300, 6, sh_degree=1)\n"
         "fr = O.forward(sc, tight=True)\n"
-        "t, fwd = hip_forward(sc, torch.device('cuda:0'))\n"
-        "v = G.state_views(fwd[5], fwd[6], fwd[7], 40000, fwd[0], 500, 300)\n"
         "u = lambda x: x.cpu().numpy().view(np.uint32)\n"
-        "assert fwd[0] == fr.R and np.array_equal(u(v['point_list']), fr.point_list)\n"
-        "assert np.array_equal(u(v['ranges']), fr.ranges)\n"
+        "for rep in range(3):\n"
+        "    t, fwd = hip_forward(sc, torch.device('cuda:0'))\n"
+        "    v = G.state_views(fwd[5], fwd[6], fwd[7], 40000, fwd[0], 500, 300)\n"
+        "    assert fwd[0] == fr.R and np.array_equal(u(v['point_list']), fr.point_list)\n"
+        "    assert np.array_equal(u(v['ranges']), fr.ranges)\n"
         "print('fallback ok')\n") % (os.path.dirname(GOLDEN.rstrip('/').rsplit('/', 1)[0]), os.path.dirname(GOLDEN))
-    env = dict(os.environ, GSR_SORT_BALLOT_RANK="1")
+    env = dict(os.environ, **{knob: "1"})
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fallback ok" in out.stdout, out.stderr[-2000:]
 
