@@ -21,11 +21,16 @@ namespace gsr {
 
 constexpr int LW_ = 11;          // window taps
 constexpr int LR_ = LW_ / 2;     // halo
-constexpr int LT_ = 16;          // output tile edge
-constexpr int LH_ = LT_ + 2 * LR_;  // 26: input tile edge
+constexpr int LTX_ = 32, LTY_ = 16;                      // output tile of one 256-thread workgroup
+constexpr int LHX_ = LTX_ + 2 * LR_, LHY_ = LTY_ + 2 * LR_;  // 42 x 26 input tile
 constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;  // loss_utils.cuh:8-9
 
 struct LossWindow { float w[LW_]; };
+
+// Both passes are register-blocked: a thread of the horizontal pass produces 4 adjacent outputs of one row from
+// 14 staged inputs (instead of 4 x 11 reads), a thread of the vertical pass 2 vertically adjacent outputs from
+// 12 filtered values per moment -- the window is walked in the same tap order as a plain 11-tap sum, so the
+// arithmetic is unchanged while LDS traffic per pixel drops ~2.5x and the halo (42 x 26 for 32 x 16) ~1.25x.
 
 // mu(q) = sum_k w[k] * f(q + k - 5)   (cross-correlation, zero padded): what conv2d computes
 __global__ __launch_bounds__(256) void k_loss_forward(const int C, const int H, const int W,
@@ -33,60 +38,84 @@ __global__ __launch_bounds__(256) void k_loss_forward(const int C, const int H, 
                                                       const LossWindow win, float* __restrict__ mapA,
                                                       float* __restrict__ mapB, float* __restrict__ mapC,
                                                       float* __restrict__ partials) {
-  __shared__ float sx[LH_][LH_ + 1], sy[LH_][LH_ + 1];
-  __shared__ float h[5][LH_][LT_ + 1];  // horizontally filtered rows
+  __shared__ float sx[LHY_][LHX_ + 1], sy[LHY_][LHX_ + 1];
+  __shared__ float h[5][LHY_][LTX_ + 1];  // horizontally filtered rows
   __shared__ float red[2][4];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int c = blockIdx.z;
-  const int x0 = blockIdx.x * LT_, y0 = blockIdx.y * LT_;
+  const int x0 = blockIdx.x * LTX_, y0 = blockIdx.y * LTY_;
   const float* X = img + (size_t)c * H * W;
   const float* Y = gt + (size_t)c * H * W;
-  for (int i = threadIdx.x; i < LH_ * LH_; i += 256) {
-    const int r = i / LH_, cc = i % LH_;
-    const int gy = y0 + r - LR_, gx = x0 + cc - LR_;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    sx[r][cc] = in ? X[(size_t)gy * W + gx] : 0.f;
-    sy[r][cc] = in ? Y[(size_t)gy * W + gx] : 0.f;
+  {  // all of a thread's halo loads are issued before the first one is consumed (one round trip, not five)
+    constexpr int NI = (LHY_ * LHX_ + 255) / 256;
+    float vx[NI], vy[NI];
+#pragma unroll
+    for (int it = 0; it < NI; it++) {
+      const int i = threadIdx.x + 256 * it, r = i / LHX_, cc = i % LHX_;
+      const int gy = y0 + r - LR_, gx = x0 + cc - LR_;
+      const bool in = i < LHY_ * LHX_ && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      vx[it] = in ? X[(size_t)gy * W + gx] : 0.f;
+      vy[it] = in ? Y[(size_t)gy * W + gx] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NI; it++) {
+      const int i = threadIdx.x + 256 * it, r = i / LHX_, cc = i % LHX_;
+      if (i < LHY_ * LHX_) { sx[r][cc] = vx[it]; sy[r][cc] = vy[it]; }
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < LH_ * LT_; i += 256) {
-    const int r = i / LT_, cc = i % LT_;
-    float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+  if (threadIdx.x < LHY_ * (LTX_ / 4)) {  // 26 rows x 8 groups of 4 outputs
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    float xv[LW_ + 3], yv[LW_ + 3];
 #pragma unroll
-    for (int k = 0; k < LW_; k++) {
-      const float xv = sx[r][cc + k], yv = sy[r][cc + k], wk = win.w[k];
-      a0 += wk * xv; a1 += wk * yv; a2 += wk * xv * xv; a3 += wk * yv * yv; a4 += wk * xv * yv;
+    for (int k = 0; k < LW_ + 3; k++) { xv[k] = sx[r][c0 + k]; yv[k] = sy[r][c0 + k]; }
+#pragma unroll
+    for (int o = 0; o < 4; o++) {
+      float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
+#pragma unroll
+      for (int k = 0; k < LW_; k++) {
+        const float xq = xv[o + k], yq = yv[o + k], wk = win.w[k];
+        a0 += wk * xq; a1 += wk * yq; a2 += wk * xq * xq; a3 += wk * yq * yq; a4 += wk * xq * yq;
+      }
+      h[0][r][c0 + o] = a0; h[1][r][c0 + o] = a1; h[2][r][c0 + o] = a2; h[3][r][c0 + o] = a3; h[4][r][c0 + o] = a4;
     }
-    h[0][r][cc] = a0; h[1][r][cc] = a1; h[2][r][cc] = a2; h[3][r][cc] = a3; h[4][r][cc] = a4;
   }
   __syncthreads();
   float l1 = 0.f, ss = 0.f;
-  const int gx = x0 + tx, gy = y0 + ty;
-  if (gx < W && gy < H) {
-    float mu1 = 0, mu2 = 0, e11 = 0, e22 = 0, e12 = 0;
+  const int tx = threadIdx.x & 31, ty0 = (threadIdx.x >> 5) * 2;  // two vertically adjacent outputs
+  float m[5][2];
 #pragma unroll
-    for (int k = 0; k < LW_; k++) {
-      const float wk = win.w[k];
-      mu1 += wk * h[0][ty + k][tx]; mu2 += wk * h[1][ty + k][tx]; e11 += wk * h[2][ty + k][tx];
-      e22 += wk * h[3][ty + k][tx]; e12 += wk * h[4][ty + k][tx];
+  for (int q = 0; q < 5; q++) {
+    float col[LW_ + 1];
+#pragma unroll
+    for (int k = 0; k < LW_ + 1; k++) col[k] = h[q][ty0 + k][tx];
+    float o0 = 0, o1 = 0;
+#pragma unroll
+    for (int k = 0; k < LW_; k++) { o0 += win.w[k] * col[k]; o1 += win.w[k] * col[k + 1]; }
+    m[q][0] = o0; m[q][1] = o1;
+  }
+#pragma unroll
+  for (int o = 0; o < 2; o++) {
+    const int gx = x0 + tx, gy = y0 + ty0 + o;
+    if (gx < W && gy < H) {
+      const float mu1 = m[0][o], mu2 = m[1][o], e11 = m[2][o], e22 = m[3][o], e12 = m[4][o];
+      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+      const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
+      const float n1 = 2.f * mu12 + SSIM_C1, n2 = 2.f * s12 + SSIM_C2;
+      const float d1 = mu1_sq + mu2_sq + SSIM_C1, d2 = s1 + s2 + SSIM_C2;
+      const float inv = 1.0f / (d1 * d2);
+      const float sv = n1 * n2 * inv;
+      // partials of s w.r.t. (mu1, sigma1_sq, sigma12) at fixed img2
+      const float ds_dmu1 = (2.f * mu2 * n2 * d1 - 2.f * mu1 * n1 * n2) * inv / d1;  // d/dmu1 of n1/d1 times n2/d2
+      const float ds_ds1 = -sv / d2;
+      const float ds_ds12 = 2.f * n1 * inv;
+      // total derivative through sigma1_sq = E[x^2] - mu1^2 and sigma12 = E[xy] - mu1*mu2:
+      const size_t oidx = ((size_t)c * H + gy) * W + gx;
+      mapA[oidx] = ds_dmu1 - 2.f * mu1 * ds_ds1 - mu2 * ds_ds12;
+      mapB[oidx] = ds_ds1;
+      mapC[oidx] = ds_ds12;
+      ss += sv;
+      l1 += fabsf(sx[ty0 + o + LR_][tx + LR_] - sy[ty0 + o + LR_][tx + LR_]);
     }
-    const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-    const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-    const float n1 = 2.f * mu12 + SSIM_C1, n2 = 2.f * s12 + SSIM_C2;
-    const float d1 = mu1_sq + mu2_sq + SSIM_C1, d2 = s1 + s2 + SSIM_C2;
-    const float inv = 1.0f / (d1 * d2);
-    const float s = n1 * n2 * inv;
-    // partials of s w.r.t. (mu1, sigma1_sq, sigma12) at fixed img2
-    const float ds_dmu1 = (2.f * mu2 * n2 * d1 - 2.f * mu1 * n1 * n2) * inv / d1;  // d/dmu1 of n1/d1 times n2/d2
-    const float ds_ds1 = -s / d2;
-    const float ds_ds12 = 2.f * n1 * inv;
-    // total derivative through sigma1_sq = E[x^2] - mu1^2 and sigma12 = E[xy] - mu1*mu2:
-    const size_t o = ((size_t)c * H + gy) * W + gx;
-    mapA[o] = ds_dmu1 - 2.f * mu1 * ds_ds1 - mu2 * ds_ds12;
-    mapB[o] = ds_ds1;
-    mapC[o] = ds_ds12;
-    ss = s;
-    l1 = fabsf(sx[ty + LR_][tx + LR_] - sy[ty + LR_][tx + LR_]);
   }
   // fixed-order workgroup reduction -> one partial pair per workgroup
 #pragma unroll
@@ -135,52 +164,84 @@ __global__ __launch_bounds__(256) void k_loss_backward(const int C, const int H,
                                                        const float* __restrict__ mapB, const float* __restrict__ mapC,
                                                        const float inv_n, const float lambda,
                                                        float* __restrict__ dL_dimg) {
-  __shared__ float s[3][LH_][LH_ + 1];
-  __shared__ float h[3][LH_][LT_ + 1];
-  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  __shared__ float s[3][LHY_][LHX_ + 1];
+  __shared__ float h[3][LHY_][LTX_ + 1];
   const int c = blockIdx.z;
-  const int x0 = blockIdx.x * LT_, y0 = blockIdx.y * LT_;
+  const int x0 = blockIdx.x * LTX_, y0 = blockIdx.y * LTY_;
   const size_t plane = (size_t)c * H * W;
-  for (int i = threadIdx.x; i < LH_ * LH_; i += 256) {
-    const int r = i / LH_, cc = i % LH_;
-    const int gy = y0 + r - LR_, gx = x0 + cc - LR_;
-    const bool in = gy >= 0 && gy < H && gx >= 0 && gx < W;
-    const size_t o = plane + (size_t)gy * W + gx;
-    s[0][r][cc] = in ? mapA[o] : 0.f;
-    s[1][r][cc] = in ? mapB[o] : 0.f;
-    s[2][r][cc] = in ? mapC[o] : 0.f;
+  const int tx = threadIdx.x & 31, ty0 = (threadIdx.x >> 5) * 2;
+  float px[2], py[2];  // this thread's two output pixels of img / gt, requested together with the halo
+  {
+    constexpr int NI = (LHY_ * LHX_ + 255) / 256;
+    float va[NI], vb[NI], vc[NI];
+#pragma unroll
+    for (int it = 0; it < NI; it++) {
+      const int i = threadIdx.x + 256 * it, r = i / LHX_, cc = i % LHX_;
+      const int gy = y0 + r - LR_, gx = x0 + cc - LR_;
+      const bool in = i < LHY_ * LHX_ && gy >= 0 && gy < H && gx >= 0 && gx < W;
+      const size_t o = plane + (size_t)gy * W + gx;
+      va[it] = in ? mapA[o] : 0.f;
+      vb[it] = in ? mapB[o] : 0.f;
+      vc[it] = in ? mapC[o] : 0.f;
+    }
+#pragma unroll
+    for (int o = 0; o < 2; o++) {
+      const int gx = x0 + tx, gy = y0 + ty0 + o;
+      const bool in = gx < W && gy < H;
+      px[o] = in ? img[plane + (size_t)gy * W + gx] : 0.f;
+      py[o] = in ? gt[plane + (size_t)gy * W + gx] : 0.f;
+    }
+#pragma unroll
+    for (int it = 0; it < NI; it++) {
+      const int i = threadIdx.x + 256 * it, r = i / LHX_, cc = i % LHX_;
+      if (i < LHY_ * LHX_) { s[0][r][cc] = va[it]; s[1][r][cc] = vb[it]; s[2][r][cc] = vc[it]; }
+    }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < LH_ * LT_; i += 256) {
-    const int r = i / LT_, cc = i % LT_;
-    float a0 = 0, a1 = 0, a2 = 0;
+  if (threadIdx.x < LHY_ * (LTX_ / 4)) {  // register-blocked as the forward: 4 adjacent outputs per thread
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
 #pragma unroll
-    for (int k = 0; k < LW_; k++) {
-      const float wk = win.w[LW_ - 1 - k];  // flipped
-      a0 += wk * s[0][r][cc + k]; a1 += wk * s[1][r][cc + k]; a2 += wk * s[2][r][cc + k];
+    for (int q = 0; q < 3; q++) {
+      float v[LW_ + 3];
+#pragma unroll
+      for (int k = 0; k < LW_ + 3; k++) v[k] = s[q][r][c0 + k];
+#pragma unroll
+      for (int o = 0; o < 4; o++) {
+        float a = 0;
+#pragma unroll
+        for (int k = 0; k < LW_; k++) a += win.w[LW_ - 1 - k] * v[o + k];  // flipped taps
+        h[q][r][c0 + o] = a;
+      }
     }
-    h[0][r][cc] = a0; h[1][r][cc] = a1; h[2][r][cc] = a2;
   }
   __syncthreads();
-  const int gx = x0 + tx, gy = y0 + ty;
-  if (gx < W && gy < H) {
-    float tA = 0, tB = 0, tC = 0;
+  float t[3][2];
 #pragma unroll
-    for (int k = 0; k < LW_; k++) {
-      const float wk = win.w[LW_ - 1 - k];
-      tA += wk * h[0][ty + k][tx]; tB += wk * h[1][ty + k][tx]; tC += wk * h[2][ty + k][tx];
+  for (int q = 0; q < 3; q++) {
+    float col[LW_ + 1];
+#pragma unroll
+    for (int k = 0; k < LW_ + 1; k++) col[k] = h[q][ty0 + k][tx];
+    float o0 = 0, o1 = 0;
+#pragma unroll
+    for (int k = 0; k < LW_; k++) { o0 += win.w[LW_ - 1 - k] * col[k]; o1 += win.w[LW_ - 1 - k] * col[k + 1]; }
+    t[q][0] = o0; t[q][1] = o1;
+  }
+#pragma unroll
+  for (int o = 0; o < 2; o++) {
+    const int gx = x0 + tx, gy = y0 + ty0 + o;
+    if (gx < W && gy < H) {
+      const size_t oi = plane + (size_t)gy * W + gx;
+      const float x = px[o], y = py[o];
+      const float d = x - y;
+      const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);  // torch: abs'(0) = 0
+      dL_dimg[oi] = (1.f - lambda) * inv_n * sgn - lambda * inv_n * (t[0][o] + 2.f * x * t[1][o] + y * t[2][o]);
     }
-    const size_t o = plane + (size_t)gy * W + gx;
-    const float x = img[o], y = gt[o];
-    const float d = x - y;
-    const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);  // torch: abs'(0) = 0
-    dL_dimg[o] = (1.f - lambda) * inv_n * sgn - lambda * inv_n * (tA + 2.f * x * tB + y * tC);
   }
 }
 
 size_t loss_workspace_bytes(int C, int H, int W) {
   const size_t maps = 3 * align_up((size_t)C * H * W * sizeof(float));
-  const size_t nblocks = (size_t)((W + LT_ - 1) / LT_) * ((H + LT_ - 1) / LT_) * C;
+  const size_t nblocks = (size_t)((W + LTX_ - 1) / LTX_) * ((H + LTY_ - 1) / LTY_) * C;
   return maps + align_up(nblocks * 2 * sizeof(float)) + ALIGN;
 }
 
@@ -191,7 +252,7 @@ hipError_t launch_photometric_loss(int C, int H, int W, const float* img, const 
   float* mapA = cv.take<float>(n);
   float* mapB = cv.take<float>(n);
   float* mapC = cv.take<float>(n);
-  const dim3 grid((W + LT_ - 1) / LT_, (H + LT_ - 1) / LT_, C);
+  const dim3 grid((W + LTX_ - 1) / LTX_, (H + LTY_ - 1) / LTY_, C);
   const int nblocks = (int)(grid.x * grid.y * grid.z);
   float* partials = cv.take<float>((size_t)nblocks * 2);
   LossWindow win;
