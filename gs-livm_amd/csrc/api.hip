@@ -223,10 +223,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   // counter, used alternately -- a forward counts into one (zero on entry) and clears the other for the next
   // forward of this thread, so a call that ends early never leaves a dirty buffer in the way.
   // GSR_DEPTH_HIST_PASS=1 restores the sort's own histogram pass (k_sort_hist_all).
-  static const bool own_hist_pass = getenv("GSR_DEPTH_HIST_PASS") != nullptr;
+  static const bool env_hist_pass = getenv("GSR_DEPTH_HIST_PASS") != nullptr;
+  const bool own_hist_pass = env_hist_pass || !preprocess_counts_depth_digits(fp, shs, colors_precomp);
   uint32_t* const ghist2 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(done_counter) + 64);
   static thread_local uint32_t hist_flip = 0;  // (not the ticket: its wrap-around skips 0 and would repeat a parity)
-  hist_flip ^= 1u;
+  if (!own_hist_pass) hist_flip ^= 1u;  // only a call that uses the pair advances it (the other buffer is clean)
   uint32_t* const ghist_acc = own_hist_pass ? nullptr : ghist2 + 1024 * hist_flip;
   uint32_t* const ghist_clear = own_hist_pass ? nullptr : ghist2 + 1024 * (hist_flip ^ 1u);
   STAGE(launch_preprocess(fp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,

@@ -202,6 +202,7 @@ struct FrameParams {
 };
 
 // ---- stage launchers (each enqueues on `s`; returns hipGetLastError()) ----
+bool preprocess_counts_depth_digits(const FrameParams& fp, const float* shs, const float* colors_precomp);
 hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const float* scales, const float* rotations,
                              const float* opacities, const float* shs, const float* cov3D_precomp,
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,

@@ -212,8 +212,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   // The depth sort's four digit histograms are counted here, where the keys are made (LDS atomics, one flush of
   // the non-empty bins per workgroup): the sort needs no histogram pass of its own.  ghist_acc is library-owned
   // and zero on entry; ghist_clear is the buffer the NEXT forward will count into.
-  __shared__ uint32_t dhist[4][256];
-  if (ghist_acc) {
+  // (not in the STAGED variant: 50 KB of SH rows + 4 KB would drop it from 3 to 2 workgroups per CU; the sort then
+  // counts its digits itself)
+  __shared__ uint32_t dhist[STAGED ? 1 : 4][STAGED ? 1 : 256];
+  if (!STAGED && ghist_acc) {
 #pragma unroll
     for (int k = 0; k < 4; k++) dhist[k][threadIdx.x] = 0u;
     if (blockIdx.x == 0)
@@ -390,7 +392,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     g.dkeysA[idx] = dkey;
     g.order[idx] = (uint32_t)idx;
   }
-  if (ghist_acc) {
+  if (!STAGED && ghist_acc) {
     // Gaussians without instances all carry the key 0xFFFFFFFF: counted per wave, not per lane (one address)
     const bool has = idx < fp.P, none = has && dkey == 0xFFFFFFFFu;
     const uint64_t nm = __ballot(none);
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   const uint32_t ws = wave_sum_u32(tiles_wg);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
   __syncthreads();
-  if (ghist_acc) {
+  if (!STAGED && ghist_acc) {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
       const uint32_t c = dhist[k][threadIdx.x];
@@ -905,20 +907,37 @@ __device__ __forceinline__ void gaussian_backward_one(
     float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
     float* __restrict__ dL_drot) {
-  const bool vis = radii[idx] > 0;
+  // Every input of the Gaussian is requested up front and unconditionally -- one memory round trip instead of one
+  // per stage (radii / touched -> record sums -> mean, covariance -> clamp bits -> scale, rotation); what a culled
+  // or untouched Gaussian reads that way is never used (selects, not arithmetic: stale bits cannot leak).
+  const int rad_in = radii[idx];
+  const uint8_t touched_in = g.touched[idx];
+  const float i_col0 = dL_dcolor[3 * idx], i_col1 = dL_dcolor[3 * idx + 1], i_col2 = dL_dcolor[3 * idx + 2];
+  const float i_mx = dL_dmean2D[3 * idx], i_my = dL_dmean2D[3 * idx + 1];
+  const float i_ca = dL_dconic[4 * idx], i_cb = dL_dconic[4 * idx + 1], i_cc = dL_dconic[4 * idx + 3];
+  const float i_op = dL_dopacity[idx];
+  const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
+  float c6[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) c6[k] = cov3D_used[6 * (size_t)idx + k];
+  const uint8_t clamped_in = g.clamped[idx];
+  float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
+  float sc_in[3] = {0.f, 0.f, 0.f};
+  if (scales) {
+    q_in = reinterpret_cast<const float4*>(rotations)[idx];
+    sc_in[0] = scales[3 * idx]; sc_in[1] = scales[3 * idx + 1]; sc_in[2] = scales[3 * idx + 2];
+  }
+  const bool vis = rad_in > 0;
   const float* sh = row ? row : shs + (size_t)idx * fp.M * 3;
   float* gs = row ? row : dL_dsh + (size_t)idx * fp.M * 3;
   // ---- gather-sum of the instance records ----
-  float gcol0 = 0, gcol1 = 0, gcol2 = 0, gmx = 0, gmy = 0, gca = 0, gcb = 0, gcc = 0, gop = 0;
   if (idx == 0) g.total[2] = 0u;  // the touched list has been consumed (k_gather_records ran before this kernel)
-  const bool was_touched = g.touched[idx] != 0;
+  const bool was_touched = touched_in != 0;
   if (was_touched) g.touched[idx] = 0;  // leave the blobs clean for another backward over them
-  if (vis && was_touched) {  // sums left by k_gather_records; everything else has no record at all
-    gcol0 = dL_dcolor[3 * idx]; gcol1 = dL_dcolor[3 * idx + 1]; gcol2 = dL_dcolor[3 * idx + 2];
-    gmx = dL_dmean2D[3 * idx]; gmy = dL_dmean2D[3 * idx + 1];
-    gca = dL_dconic[4 * idx]; gcb = dL_dconic[4 * idx + 1]; gcc = dL_dconic[4 * idx + 3];
-    gop = dL_dopacity[idx];
-  }
+  const bool rec = vis && was_touched;  // sums left by k_gather_records; everything else has no record at all
+  const float gcol0 = rec ? i_col0 : 0.f, gcol1 = rec ? i_col1 : 0.f, gcol2 = rec ? i_col2 : 0.f;
+  const float gmx = rec ? i_mx : 0.f, gmy = rec ? i_my : 0.f;
+  const float gca = rec ? i_ca : 0.f, gcb = rec ? i_cb : 0.f, gcc = rec ? i_cc : 0.f, gop = rec ? i_op : 0.f;
   dL_dmean2D[3 * idx] = gmx; dL_dmean2D[3 * idx + 1] = gmy; dL_dmean2D[3 * idx + 2] = 0.f;
   dL_dconic[4 * idx] = gca; dL_dconic[4 * idx + 1] = gcb; dL_dconic[4 * idx + 2] = 0.f; dL_dconic[4 * idx + 3] = gcc;
   dL_dopacity[idx] = gop;
@@ -933,11 +952,7 @@ __device__ __forceinline__ void gaussian_backward_one(
     dL_drot[4 * idx] = 0.f; dL_drot[4 * idx + 1] = 0.f; dL_drot[4 * idx + 2] = 0.f; dL_drot[4 * idx + 3] = 0.f;
     return;
   }
-  const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
   // ---- B2: conic -> cov2D -> cov3D and mean (backward.cu:140-275) ----
-  float c6[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) c6[k] = cov3D_used[6 * (size_t)idx + k];
   const Ewa e = ewa_project(mx, my, mz, fp, c6, V);
   const float limx = 1.3f * fp.tan_fovx, limy = 1.3f * fp.tan_fovy;
   const float xmul = (e.txtz < -limx || e.txtz > limx) ? 0.f : 1.f;
@@ -993,7 +1008,7 @@ __device__ __forceinline__ void gaussian_backward_one(
   }
   // ---- SH backward (backward.cu:20-135) ----
   if (shs && !colors_are_precomp) {
-    const uint8_t cb = g.clamped[idx];
+    const uint8_t cb = clamped_in;
     const float gr[3] = {(cb & 1) ? 0.f : gcol0, (cb & 2) ? 0.f : gcol1, (cb & 4) ? 0.f : gcol2};
     const float q0 = mx - campos[0], q1 = my - campos[1], q2 = mz - campos[2];
     const float len = sqrtf(q0 * q0 + q1 * q1 + q2 * q2);
@@ -1068,10 +1083,9 @@ __device__ __forceinline__ void gaussian_backward_one(
   dL_dmean3D[3 * idx] = dm0; dL_dmean3D[3 * idx + 1] = dm1; dL_dmean3D[3 * idx + 2] = dm2;
   // ---- covariance -> scale / rotation (backward.cu:279-366) ----
   if (scales) {
-    const float4 q = reinterpret_cast<const float4*>(rotations)[idx];
+    const float4 q = q_in;
     const float r = q.x, x = q.y, y = q.z, z = q.w;
-    const float s[3] = {fp.scale_modifier * scales[3 * idx], fp.scale_modifier * scales[3 * idx + 1],
-                        fp.scale_modifier * scales[3 * idx + 2]};
+    const float s[3] = {fp.scale_modifier * sc_in[0], fp.scale_modifier * sc_in[1], fp.scale_modifier * sc_in[2]};
     float R[3][3];  // R[c][r]
     R[0][0] = 1.f - 2.f * (y * y + z * z); R[0][1] = 2.f * (x * y - r * z); R[0][2] = 2.f * (x * z + r * y);
     R[1][0] = 2.f * (x * y + r * z); R[1][1] = 1.f - 2.f * (x * x + z * z); R[1][2] = 2.f * (y * z - r * x);
@@ -1152,6 +1166,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float* 
 }
 
 // ---------------------------------- launchers ----------------------------------------------------
+// whether k_preprocess counts the depth sort's digit histograms for this call (not in the LDS-staged SH variant)
+bool preprocess_counts_depth_digits(const FrameParams& fp, const float* shs, const float* colors_precomp) {
+  return !((shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0);
+}
+
 hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const float* scales, const float* rotations,
                              const float* opacities, const float* shs, const float* cov3D_precomp,
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,
