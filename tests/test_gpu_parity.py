@@ -313,8 +313,12 @@ def test_randomised_scenes(gpu_device):
     count, anisotropy and opacity ranges, background, scale modifier, non-unit quaternions -- through the full
     forward + backward comparison: integer stages bit-exact, images to 1e-4, gradients to the conditioning-aware
     bound of helpers.grad_close (the scenes contain nearly singular conics and screen-filling splats)."""
-    rng = np.random.default_rng(20240611)
-    for case in range(12):
+    _random_scenes(np.random.default_rng(20240611), 12, gpu_device)
+
+
+def _random_scenes(rng, ncases, gpu_device):
+    """(also driven with other generator seeds by tools/soak_random_scenes.py)"""
+    for case in range(ncases):
         W, H = int(rng.integers(17, 700)), int(rng.integers(9, 420))
         P = int(rng.integers(50, 30_000))
         D = int(rng.integers(0, 4))

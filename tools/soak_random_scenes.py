@@ -1,0 +1,21 @@
+"""Soak run of the randomised parity check of tests/test_gpu_parity.py with fresh generator seeds (GPU):
+    python tools/soak_random_scenes.py [first_seed] [n_seeds] [cases_per_seed]
+Every case goes through the full forward + backward comparison against the CPU oracle; the first failure aborts."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import torch
+
+import test_gpu_parity as T
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 1
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+cases = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+dev = torch.device("cuda:0")
+for seed in range(first, first + n):
+    T._random_scenes(np.random.default_rng(seed), cases, dev)
+    print("generator seed %d: %d cases ok" % (seed, cases), flush=True)
