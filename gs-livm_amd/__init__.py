@@ -4,6 +4,7 @@ Layout (only what the hot path needs):
   csrc/            hand-written HIP kernels (gfx950) + the C ABI (include/gsraster.h) + LibTorch binding
   _capi.py         ctypes binding of the C ABI (mirrors src/gs/rasterize_points.cu)
   rasterizer.py    host-side mirror of the reference operator surface (src/gs/rasterizer.cu)
+  render_utils.py  Camera (rasterizer-facing part) and render() as in include/gs/gs/render_utils.cuh
   loss.py          fused L1 + SSIM photometric loss (SURVEY.md 8(f) "next" row 2)
   model.py         fused activations + Adam for the caller's leaf tensors (SURVEY.md 8(f) "next" row 1)
   synthetic.py     synthetic scenes of SURVEY.md section 8(d) for tests and bench
@@ -20,6 +21,7 @@ from .model import FusedActivations, FusedAdam, GaussianParameters, GrowableAdam
 from . import ply  # noqa: F401
 from .rasterizer import (GaussianRasterizationSettings, GaussianRasterizer,  # noqa: F401
                          rasterize_gaussians)
+from .render_utils import Camera, get_projection_matrix, render  # noqa: F401
 
 
 
@@ -39,5 +41,5 @@ def torch_ops():
     return mod
 
 
-__all__ = ["PhotometricLoss", "photometric_loss", "reference_window_1d", "FusedActivations", "FusedAdam", "GaussianParameters", "GrowableAdam", "GrowableGaussians", "ply", "GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "rasterize_forward",
+__all__ = ["PhotometricLoss", "photometric_loss", "reference_window_1d", "FusedActivations", "FusedAdam", "GaussianParameters", "GrowableAdam", "GrowableGaussians", "ply", "GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "Camera", "render", "get_projection_matrix", "rasterize_forward",
            "rasterize_backward", "mark_visible", "state_views", "lib", "torch_ops", "synthetic", "multiview", "GsrError", "LIB_PATH"]

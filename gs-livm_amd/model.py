@@ -96,6 +96,10 @@ class GaussianParameters(torch.nn.Module):
     def Get_xyz(self):
         return self._xyz
 
+    def Get_max_sh_degree(self):
+        m = 1 + int(self._features_rest.shape[1])  # coefficients per channel = (degree + 1)^2
+        return int(round(m ** 0.5)) - 1
+
     def Get_opacity(self):
         return self.activated()[1]
 

@@ -397,6 +397,41 @@ def test_autograd_surface_several_views_one_backward(gpu_device):
         grad_close(leaves[leaf].grad.cpu().numpy(), want[k].astype(np.float32), k)
 
 
+def test_render_mirror_equals_the_operator_call(gpu_device):
+    """G.render (include/gs/gs/render_utils.cuh:13-56) = settings from the Camera + activated model + one rasterizer
+    call: same images as calling the operator by hand, and its backward reaches the raw leaves."""
+    import math
+    dev = gpu_device
+    P, W, H, D = 4000, 200, 120, 2
+    g = S.make_gaussians(P, 31, sh_degree=D, aspect=W / H)
+    raw = dict(xyz=g["means3D"], f_dc=g["shs"][:, :1], f_rest=g["shs"][:, 1:], scaling=np.log(g["scales"]),
+               rotation=g["rotations"] * 1.7, opacity=np.log(g["opacities"] / (1 - g["opacities"])))
+    t = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)).to(dev) for k, v in raw.items()}
+    model = G.GaussianParameters(t["xyz"], t["f_dc"], t["f_rest"], t["scaling"], t["rotation"], t["opacity"])
+    assert model.Get_max_sh_degree() == D
+    a = math.radians(5.0)
+    R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], np.float32)
+    fovx = math.radians(60.0)
+    cam = G.Camera(R, (0.0, 0.1, -0.2), fovx, 2.0 * math.atan(math.tan(fovx / 2.0) * H / W), W, H, device=dev)
+    bg = torch.tensor([0.2, 0.5, 0.9])
+    color, depth, acc = G.render(cam, model, bg, 1.1)
+    assert color.shape == (3, H, W) and depth.shape == (1, H, W) and acc.shape == (1, H, W)
+    st = G.GaussianRasterizationSettings(H, W, math.tan(fovx * 0.5), math.tan(cam.Get_FoVy() * 0.5), bg.to(dev), 1.1,
+                                         cam.Get_world_view_transform(), cam.Get_full_proj_transform(), D,
+                                         cam.Get_camera_center(), False)
+    with torch.no_grad():
+        xyz, op, sc, rot, shs = model.activated()
+        c2, _, d2, a2 = G.GaussianRasterizer(st)(xyz, torch.zeros_like(xyz), op, shs=shs, scales=sc, rotations=rot)
+    assert torch.equal(color, c2) and torch.equal(depth, d2) and torch.equal(acc, a2)
+    (color.sum() + acc.sum()).backward()
+    for p in model.parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all()
+    assert float(model._xyz.grad.abs().sum()) > 0 and float(model._features_rest.grad.abs().sum()) > 0
+    # precomputed colours through override_color
+    col, _, _ = G.render(cam, model, bg, 1.1, override_color=torch.full((P, 3), 0.25, device=dev))
+    assert float((col - color).abs().max()) > 0
+
+
 def test_cpp_libtorch_surface_matches_c_abi_path(gpu_device):
     """The C++/LibTorch binding GS-LIVM would link (csrc/torch_binding.cpp): RasterizeGaussiansCUDA /
     ...BackwardCUDA give bit-identical results to the ctypes route (same C ABI underneath), and the

@@ -83,6 +83,26 @@ def test_camera_conventions():
     assert np.isclose(cam["tanfovx"], math.tan(math.radians(30)))
 
 
+def test_camera_mirror_has_the_reference_getters_and_matrices():
+    """G.Camera = the rasterizer-facing part of the reference's Camera (src/gs/camera.cu:14-57): the tensors are the
+    transposed matrices, full_proj = view @ projection, the centre is row 3 of the inverse view."""
+    a = math.radians(-11.0)
+    R = np.array([[math.cos(a), 0, math.sin(a)], [0, 1, 0], [-math.sin(a), 0, math.cos(a)]], np.float32)
+    fovx = math.radians(70.0)
+    fovy = 2.0 * math.atan(math.tan(fovx / 2.0) * 480 / 640)
+    cam = G.Camera(R, (0.3, -0.1, 0.7), fovx, fovy, 640, 480, device="cpu", uid=4, image_name="kf4")
+    ref = S.make_camera(640, 480, fovx_deg=70.0, yaw_deg=-11.0, position=(0.3, -0.1, 0.7))
+    assert np.array_equal(cam.Get_world_view_transform().numpy(), ref["viewmatrix"])
+    assert np.array_equal(cam.Get_full_proj_transform().numpy(), ref["projmatrix"])
+    assert np.allclose(cam.Get_camera_center().numpy(), ref["campos"], atol=1e-6)
+    assert (cam.Get_image_width(), cam.Get_image_height(), cam.Get_uid(), cam.Get_image_name()) == (640, 480, 4, "kf4")
+    assert np.isclose(math.tan(cam.Get_FoVx() * 0.5), ref["tanfovx"]) and np.isclose(math.tan(cam.Get_FoVy() * 0.5),
+                                                                                     ref["tanfovy"])
+    P = G.get_projection_matrix(S.ZNEAR, S.ZFAR, fovx, fovy)  # the tensor = P transposed (Eigen memory, camera.cu:78-81)
+    assert P[2, 3] == 1 and np.isclose(float(P[2, 2]), 100 / 99.99) and np.isclose(float(P[3, 2]), -1 / 99.99)
+    assert np.array_equal(cam.Get_projection_matrix().numpy(), P.numpy())
+
+
 def test_scene_generator_is_seeded_and_exercises_culls():
     a, b = S.make_scene(5000, 320, 240, 9, 1), S.make_scene(5000, 320, 240, 9, 1)
     assert all(np.array_equal(a[k], b[k]) for k in ("means3D", "scales", "rotations", "opacities", "shs"))
