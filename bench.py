@@ -12,15 +12,17 @@ reference's groups / learning rates.  Activations and Adam run as the fused HIP 
 (SURVEY.md 8(f) "next" row 1) unless --torch-optimizer selects the reference's separate Torch ops.
 Inputs are resident in HBM before the timed region.  value = Mpixels/s of the whole job.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): the flat Gaussian buffer is broadcast from
-rank 0 once, rank r renders view r of the same scene (yaw offsets of SURVEY.md 8(d)) forward + backward, the
-per-view gradients are summed with ONE all-reduce of the flat gradient buffer (112 MB at M = 1) and every rank
-applies the identical Adam step to its replica (--sync-mode owner selects the reduce-to-owner +
-per-step parameter broadcast variant instead).  The rasterizer itself never communicates.  scaling = "weak".
+N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): rank r renders view r of the same scene (yaw
+offsets of SURVEY.md 8(d)).  Default --sync-mode scatter = BASELINE config 4 as worded: the flat Gaussian buffer is
+broadcast from rank 0 ONCE before the loop, then every rank runs the full step on its own view with no collective
+per step (the path has no exchange step).  --sync-mode allreduce sums the per-view gradients with one all-reduce of
+the flat gradient buffer (112 MB at M = 1) per step and every rank applies the identical Adam step to its replica
+(SURVEY.md 8(e)); --sync-mode owner = reduce to rank 0 + parameter broadcast.  The rasterizer itself never
+communicates.  scaling = "weak".
 
 Extra objects on the JSON line: "roofline" (dominant kernel, algorithmic bytes / hipEvent-measured launch
 time vs 8 TB/s), "cpu_baseline" (the CPU oracle on the same workload, host cores, rank 0 at N = 1 only),
-"kernels" (per-kernel ms per step) and "workload_stats" (measured P_vis, R, list lengths).
+"kernels" (per-kernel ms per step), "whole_path", "workload_stats" (measured P_vis, R, list lengths) and "work_units".
 """
 import argparse
 import json
@@ -303,7 +305,8 @@ def main():
     except (OSError, ValueError):
         pass
     roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), traffic=traffic,
+                    frac=round(achieved / HBM_PEAK_GBS, 4), frac_of_achievable_6300=round(achieved / 6300.0, 4),
+                    traffic=traffic,
                     algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_ms=round(kernels[dom]["avg_launch_ms"], 4))
     # Context for a kernel that is not HBM-bound (the blend kernels): its VALU issue floor from the committed SQ
     # counter summary (tools/sq_summary.py): wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz).
@@ -359,6 +362,18 @@ def main():
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in d.items()}
                     for k, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         "workload_stats": stats,
+        # SURVEY.md 8(d) work units: instances through the binning per second of step time, and (pixel, contributor)
+        # pairs per second of each blend kernel's own time (contributors = n_contrib summed over the image)
+        "work_units": {
+            "Minstances_per_s": round(stats["R"] / (ms_per_step * 1e-3) / 1e6, 1),
+            "Minstances_per_s_reference_binning": round(stats["R_reference_binning"] / (ms_per_step * 1e-3) / 1e6, 1),
+            "Gpairs_per_s_blend_forward": (round(stats["mean_contrib_per_pixel"] * W * H /
+                                                 (kernels["k_blend_forward"]["avg_launch_ms"] * 1e-3) / 1e9, 2)
+                                           if "k_blend_forward" in kernels else None),
+            "Gpairs_per_s_blend_backward": (round(stats["mean_contrib_per_pixel"] * W * H /
+                                                  (kernels["k_blend_backward"]["avg_launch_ms"] * 1e-3) / 1e9, 2)
+                                            if "k_blend_backward" in kernels else None),
+        },
     }
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not args.forward_only:
