@@ -246,7 +246,7 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
 // per pass; `ghist` = the [4][256] digit histograms if the producer of the keys counted them (k_preprocess
 // does), else null and k_sort_hist_all counts them first.  Pairs start in (keysA, valsA) and end
 // there.  sc.words (ghist | tickets | status) must be zero on entry: k_preprocess clears it.
-template <int TILE>
+template <int TILE, int NW>
 static void depth_sort_passes(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
                               int n, bool arank, const uint32_t* ghist, hipStream_t s) {
   const int ntiles = (n + TILE - 1) / TILE;
@@ -258,11 +258,11 @@ static void depth_sort_passes(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB,
     uint32_t* kout = inA ? keysB : keysA;
     uint32_t* vout = inA ? valsB : valsA;
     if (arank)
-      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true, 4, TILE>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout, n,
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true, NW, TILE>), dim3(ntiles), dim3(64 * NW), 0, s, kin, vin, kout, vout, n,
                          8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, ghist + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     else
-      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false, 4, TILE>), dim3(ntiles), dim3(256), 0, s, kin, vin, kout, vout,
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false, NW, TILE>), dim3(ntiles), dim3(64 * NW), 0, s, kin, vin, kout, vout,
                          n, 8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, ghist + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     inA = !inA;
@@ -279,10 +279,13 @@ hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
     hipLaunchKernelGGL(k_sort_hist_all, dim3(nwg < 256 ? nwg : 256), dim3(256), 0, s, keysA, n, sc.ghist());
   }
   const bool arank = lds_atomic_rank_ok(s);
-  if (depth_sort_tile((size_t)n) == (size_t)SORT_TILE_SMALL)
-    depth_sort_passes<SORT_TILE_SMALL>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, s);
+  const size_t tile = depth_sort_tile((size_t)n);
+  if (tile == (size_t)SORT_TILE_SMALL)
+    depth_sort_passes<SORT_TILE_SMALL, 4>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, s);
+  else if (tile == (size_t)SORT_TILE)
+    depth_sort_passes<SORT_TILE, 4>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, s);
   else
-    depth_sort_passes<SORT_TILE>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, s);
+    depth_sort_passes<SORT_TILE_BIG, 8>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, s);
   return hipGetLastError();
 }
 
