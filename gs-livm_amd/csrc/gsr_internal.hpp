@@ -303,6 +303,25 @@ struct ProfScope {  // records a start/stop event pair around the launches in it
 // integer pixel radius `radius` centred at (px,py); float arithmetic with truncating casts, exactly
 // as the reference so the rectangle (and hence every sort key) matches bit for bit.  Only
 // add/sub and a division by 16 are involved, so FMA contraction cannot change the result.
+// Upper bound of ln(x) for normal x > 0 from +, *, / only (IEEE, no contraction in this file), so the CPU
+// oracle reproduces it bit for bit -- unlike a hardware log -- and the culled tile rectangles stay an
+// exact-match quantity: ln x = e ln 2 + 2 atanh((m-1)/(m+1)), series cut after t^5 (remainder < 1.6e-4).
+__device__ __forceinline__ float ln_upper(float x) {
+  const uint32_t b = __float_as_uint(x);
+  const int e = (int)(b >> 23) - 127;
+  const float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);  // [1, 2)
+  const float t = (m - 1.0f) / (m + 1.0f);
+  const float t2 = t * t;
+  const float s = t * (2.0f + t2 * (0.6666667f + t2 * 0.4f));
+  return (float)e * 0.6931472f + s + 3e-4f;
+}
+
+// Footprint threshold of a splat of opacity op: a pixel can only receive alpha = min(.99, op e^power) >= 1/255 if
+// -power <= ln(255 op); tau bounds that from above with slack for the rounding of the blend kernels' own power /
+// exp arithmetic (1 % + 0.02).  Used by k_preprocess (footprint box, tile culling) and by the blend kernels
+// (exact ellipse-vs-quad test).
+__device__ __forceinline__ float footprint_tau(float op) { return ln_upper(255.0f * op) * 1.01f + 0.02f; }
+
 __host__ __device__ inline void tile_rect(float px, float py, int radius, int gx, int gy, int& x0, int& y0, int& x1,
                                           int& y1) {
   const float r = (float)radius;

@@ -29,19 +29,6 @@ __device__ __forceinline__ float ndc_to_pix(float v, int S) {
   return (float)((((double)v + 1.0) * (double)S - 1.0) * 0.5);
 }
 
-// Upper bound of ln(x) for normal x > 0 from +, *, / only (IEEE, no contraction in this file), so the CPU
-// oracle reproduces it bit for bit -- unlike a hardware log -- and the culled tile rectangles stay an
-// exact-match quantity: ln x = e ln 2 + 2 atanh((m-1)/(m+1)), series cut after t^5 (remainder < 1.6e-4).
-__device__ __forceinline__ float ln_upper(float x) {
-  const uint32_t b = __float_as_uint(x);
-  const int e = (int)(b >> 23) - 127;
-  const float m = __uint_as_float((b & 0x007FFFFFu) | 0x3F800000u);  // [1, 2)
-  const float t = (m - 1.0f) / (m + 1.0f);
-  const float t2 = t * t;
-  const float s = t * (2.0f + t2 * (0.6666667f + t2 * 0.4f));
-  return (float)e * 0.6931472f + s + 3e-4f;
-}
-
 __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
@@ -344,7 +331,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
           if (op < 1.0f / 255.0f) {
             hx = hy = -1e30f;  // box test can never pass
           } else {
-            const float tau = ln_upper(255.0f * op) * 1.01f + 0.02f;
+            const float tau = footprint_tau(op);
             const float dc = conx * conz - cony * cony;
             if (conx > 0.0f && conz > 0.0f && dc > 0.0f) {
               hx = sqrtf(2.0f * tau * conz / dc) + 0.05f;

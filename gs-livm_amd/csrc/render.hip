@@ -100,6 +100,39 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// Exact-conservative ellipse-vs-quad test.  f(u, v) = 1/2 (A u^2 + C v^2) + B u v = -power of a pixel at offset (u, v)
+// from the splat centre; the pixel centres of a quad fill [x0, x0 + 7] x [y0, y0 + 7].  f is convex (the caller
+// only asks for positive-definite conics), so its minimum over the rectangle is 0 if the centre lies inside and
+// otherwise sits on one of the four edges, where it is a clamped 1-D minimisation.  min f > tau means that no pixel
+// of the quad can reach alpha >= 1/255 (tau carries the slack, footprint_tau): the quad skips the splat exactly as
+// the reference skips it pixel by pixel (forward.cu:374-376, backward.cu:476-478).  The footprint BOX alone lets
+// ~25 % of the (quad, splat) pairs through that this test rejects (corners of slanted ellipses).
+__device__ __forceinline__ bool ellipse_reaches_quad(float cx, float cy, float A, float B, float C, float tau,
+                                                     float x0, float y0) {
+  const float u0 = x0 - cx, u1 = u0 + 7.0f, v0 = y0 - cy, v1 = v0 + 7.0f;
+  if (u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f) return true;
+  const float nBiC = -B * __builtin_amdgcn_rcpf(C), nBiA = -B * __builtin_amdgcn_rcpf(A);
+  float fmin = 3.0e38f;
+#pragma unroll
+  for (int e = 0; e < 2; e++) {
+    const float ue = e ? u1 : u0;
+    const float v = fminf(fmaxf(nBiC * ue, v0), v1);
+    fmin = fminf(fmin, 0.5f * (A * ue * ue + C * v * v) + B * ue * v);
+    const float ve = e ? v1 : v0;
+    const float u = fminf(fmaxf(nBiA * ve, u0), u1);
+    fmin = fminf(fmin, 0.5f * (A * u * u + C * ve * ve) + B * u * ve);
+  }
+  return fmin <= tau;
+}
+
+// hit test of one splat against one quad: footprint box first (hx < 0: never, hx >= 1e6: indefinite conic, no
+// culling), then the ellipse itself
+__device__ __forceinline__ bool splat_hits_quad(const float4 a, const float4 b, const float4 c, float x0, float y0) {
+  const bool box = (a.x + c.z >= x0) && (a.x - c.z <= x0 + 7.0f) && (a.y + c.w >= y0) && (a.y - c.w <= y0 + 7.0f);
+  if (!box || c.z >= 1.0e6f) return box;
+  return ellipse_reaches_quad(a.x, a.y, a.z, a.w, b.x, footprint_tau(b.y), x0, y0);
+}
+
 // Footprint box of a splat vs the four 8x8 quads of the tile at (tx0, ty0); bit q set = may touch.
 __device__ __forceinline__ uint32_t quad_hits(float x, float y, float hx, float hy, float tx0, float ty0) {
   const float xl = x - hx, xh = x + hx, yl = y - hy, yh = y + hy;
@@ -160,7 +193,7 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
     a = splats[(size_t)id * SPLAT_F4 + 0];
     b = splats[(size_t)id * SPLAT_F4 + 1];
     c = splats[(size_t)id * SPLAT_F4 + 2];
-    hit = (a.x + c.z >= qx0) && (a.x - c.z <= qx0 + 7.0f) && (a.y + c.w >= qy0) && (a.y - c.w <= qy0 + 7.0f);
+    hit = splat_hits_quad(a, b, c, qx0, qy0);
   }
   for (int base = 0; base < n && !wave_done; base += 64) {
     // published conic terms carry the constant factors of power = -1/2 (A dx^2 + C dy^2) - B dx dy and the
@@ -178,7 +211,7 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
       a = splats[(size_t)id * SPLAT_F4 + 0];
       b = splats[(size_t)id * SPLAT_F4 + 1];
       c = splats[(size_t)id * SPLAT_F4 + 2];
-      hit = (a.x + c.z >= qx0) && (a.x - c.z <= qx0 + 7.0f) && (a.y + c.w >= qy0) && (a.y - c.w <= qy0 + 7.0f);
+      hit = splat_hits_quad(a, b, c, qx0, qy0);
     }
     // Visit loop, software-pipelined by hand: the LDS broadcast reads of the NEXT hit are issued before the
     // current hit is blended (two register sets, no copies), so their latency hides behind ~30 VALU ops.
@@ -314,6 +347,14 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       sId[tid] = id;
       sSlot[tid] = si.x + (uint32_t)(((int)blockIdx.y - y0) * rw + ((int)blockIdx.x - x0));
       hits = quad_hits(a.x, a.y, c.z, c.w, tx0, ty0);
+      if (hits && c.z < 1.0e6f) {  // box passed: ask the ellipse itself, quad by quad
+        const float tau = footprint_tau(b.y);
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (((hits >> q) & 1u) &&
+              !ellipse_reaches_quad(a.x, a.y, a.z, a.w, b.x, tau, tx0 + (float)((q & 1) * 8), ty0 + (float)((q >> 1) * 8)))
+            hits &= ~(1u << q);
+      }
     }
     if (w < LW) {
 #pragma unroll
