@@ -60,8 +60,10 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
         # sort pass, which therefore reads descriptors instead of pairs): per-launch AVERAGE of the two scatter passes
         "k_emit": (R * 1 + P_vis * 16) if kb == 2 else (R * (kb + 4) + P_vis * 16),
         "k_sort_hist": R * kb,
-        "k_sort_scatter": (R * (kb + 4) * 3 + P_vis * 16) // 2 if kb == 2 else R * 2 * (kb + 4),
-        "k_tile_ranges": R * kb + tiles * 8,
+        # (first pass: descriptors in, pairs out; second pass: pairs in, ids out -- the sorted tile ids are not written)
+        "k_sort_scatter": (R * ((kb + 4) * 2 + 4) + P_vis * 16) // 2 if kb == 2 else R * 2 * (kb + 4),
+        # 16-bit keys: ranges come from the last pass's per-tile counts (scan of T counters), no key read
+        "k_tile_ranges": tiles * 16 if kb == 2 else R * kb + tiles * 8,
         "k_sort_scan_chunks": (R // 4096 + 1) * 2048, "k_sort_scan_top": 0,
         "k_blend_forward": R * 44 + W * H * 28,                   # full lists (early exit reads fewer)
         "k_blend_backward": W * H * 24 + R_bwd * (40 + 36),       # SURVEY.md 8(d) per-instance figures x walked entries

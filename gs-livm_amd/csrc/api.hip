@@ -284,9 +284,18 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
                     b.inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16,
                     /*store_pairs=*/!key16, stream));  // 16-bit keys: the pairs are generated inside the first sort pass
   const EmitFusion ef = {fp, g, R, b.chunk_first};
+  // 16-bit keys and at least two passes: the last pass counts the instances of every tile into the zeroed ranges
+  // instead of writing the sorted keys, and a one-workgroup scan turns the counts into ranges; otherwise the range
+  // kernel reads the sorted keys as the reference's identifyTileRanges does
+  static const bool ranges_from_keys = getenv("GSR_RANGES_FROM_KEYS") != nullptr;  // diagnostics / fallback
+  const bool count_ranges = key16 && sort_passes(tile_bits) >= 2 && !ranges_from_keys;
   STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, R, tile_bits, start_in_A,
-                          /*is_depth_sort=*/false, key16, /*first_hist_done=*/true, key16 ? &ef : nullptr, stream));
-  STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, key16, stream));
+                          /*is_depth_sort=*/false, key16, /*first_hist_done=*/true, key16 ? &ef : nullptr,
+                          count_ranges ? reinterpret_cast<uint32_t*>(im.ranges) : nullptr, stream));
+  if (count_ranges)
+    STAGE(launch_ranges_from_counts(im.ranges, tiles, stream));
+  else
+    STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, key16, stream));
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
   return R;
 }

@@ -235,9 +235,11 @@ hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningStat
 // (keysA, valsA) and (keysB, valsB), starting in A when start_in_A.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
                              int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
-                             bool first_hist_done, const EmitFusion* fused_first_pass, hipStream_t s);
+                             bool first_hist_done, const EmitFusion* fused_first_pass, uint32_t* key_count,
+                             hipStream_t s);
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
                              int n, const uint32_t* ghist, hipStream_t s);
+hipError_t launch_ranges_from_counts(uint2* ranges, int T, hipStream_t s);
 hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, bool key16, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, hipStream_t s);

@@ -179,7 +179,7 @@ static bool lds_atomic_rank_ok(hipStream_t s) {
 template <typename K>
 static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t* valsB, SortScratch sc, int n,
                                   int end_bit, bool start_in_A, bool is_depth_sort, bool first_hist_done,
-                                  const EmitFusion* ef, hipStream_t s) {
+                                  const EmitFusion* ef, uint32_t* key_count, hipStream_t s) {
   const int kb = is_depth_sort ? (int)K_DSORT_HIST - (int)K_SORT_HIST : 0;  // profiler ids of this sort
   // tile geometry of the instance sort (both key widths use the same today; see TSORT_TILE)
   constexpr int TT = sizeof(K) == 2 ? TSORT_TILE : SORT_TILE, NWV = sizeof(K) == 2 ? TSORT_WAVES : 4;
@@ -213,6 +213,17 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
       const hipError_t e = launch_emit_scatter(*ef, reinterpret_cast<uint16_t*>(kout), vout, nbits, sc.counts,
                                                sc.chunk_sums, sc.digit_base, arank, s);
       if (e != hipSuccess) return e;
+    } else if (key_count && p == passes - 1 && p > 0 && sizeof(K) == 2) {
+      // last pass of the instance sort: per-key counts instead of the sorted keys (sort_core.hpp, COUNT)
+      ProfScope ps(K_SORT_SCATTER + kb, s);
+      if (arank)
+        hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT, true>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout,
+                           vout, n, shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, key_count);
+      else
+        hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT, true>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout,
+                           vout, n, shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
+                           (uint32_t*)nullptr, key_count);
     } else {
       ProfScope ps(K_SORT_SCATTER + kb, s);
       if (arank)
@@ -233,13 +244,15 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
 // buffers are the same allocations, viewed as uint16_t.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
                              int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
-                             bool first_hist_done, const EmitFusion* fused_first_pass, hipStream_t s) {
+                             bool first_hist_done, const EmitFusion* fused_first_pass, uint32_t* key_count,
+                             hipStream_t s) {
   if (n <= 0) return hipSuccess;
   if (key16)
     return sort_pairs_impl<uint16_t>(reinterpret_cast<uint16_t*>(keysA), valsA, reinterpret_cast<uint16_t*>(keysB),
-                                     valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done, fused_first_pass, s);
+                                     valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done, fused_first_pass,
+                                     key_count, s);
   return sort_pairs_impl<uint32_t>(keysA, valsA, keysB, valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done,
-                                   nullptr, s);
+                                   nullptr, nullptr, s);
 }
 
 // Depth sort of the P (depth bits, Gaussian id) pairs: 32-bit keys, four 8-bit passes, one look-back scatter launch
@@ -320,6 +333,43 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys,
       prev = k[j];
     }
   }
+}
+
+// Ranges from the per-tile instance counts the last sort pass left in ranges[t].y (ranges[t].x still zero): one
+// workgroup scans them; tiles without instances keep the reference's (0, 0) (its cudaMemset, rasterizer_impl.cu:311).
+__global__ __launch_bounds__(1024) void k_ranges_from_counts(uint2* __restrict__ ranges, const int T) {
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (tid == 0) carry_s = 0u;
+  __syncthreads();
+  for (int t0 = 0; t0 < T; t0 += 1024 * 4) {
+    const int i0 = t0 + tid * 4;
+    uint32_t c[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[k] = i0 + k < T ? ranges[i0 + k].y : 0u;
+    const uint32_t sum = c[0] + c[1] + c[2] + c[3];
+    const uint32_t inc = wave_incl_scan(sum, lane);
+    if (lane == 63) wsum[w] = inc;
+    __syncthreads();
+    uint32_t base = carry_s;
+    for (int k = 0; k < w; k++) base += wsum[k];
+    uint32_t run = base + inc - sum;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      if (i0 + k < T) ranges[i0 + k] = c[k] ? make_uint2(run, run + c[k]) : make_uint2(0u, 0u);
+      run += c[k];
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = run;
+    __syncthreads();
+  }
+}
+
+hipError_t launch_ranges_from_counts(uint2* ranges, int T, hipStream_t s) {
+  ProfScope ps(K_TILE_RANGES, s);
+  hipLaunchKernelGGL(k_ranges_from_counts, dim3(1), dim3(1024), 0, s, ranges, T);
+  return hipGetLastError();
 }
 
 hipError_t launch_tile_ranges(const uint32_t* keys, int R, uint2* ranges, bool key16, hipStream_t s) {

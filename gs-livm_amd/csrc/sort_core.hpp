@@ -64,13 +64,20 @@ struct ScatterLds {
   uint32_t lval[TILE];
 };
 
-template <typename K, bool LB, bool ARANK, int NW, int TILE>
+// COUNT (last pass of the instance sort, NW == 4): the sorted keys are not written at all; instead the pass counts
+// the instances of every full key (= tile id) into key_count[key * 2 + 1] -- the .y of the tile's zeroed range --
+// from which k_ranges_from_counts derives the per-tile ranges.  The input of the last pass is sorted by the lower
+// digits and the pass is stable, so every digit group of the reordered workgroup tile is sorted by its low part
+// and holds very few distinct ones: the digit's thread finds their boundaries by bisection and issues one global
+// atomic per distinct key.  Saves the sorted-key write, the range kernel's read of it, and most of that kernel.
+template <typename K, bool LB, bool ARANK, int NW, int TILE, bool COUNT = false>
 __device__ __forceinline__ void scatter_core(ScatterLds<K, NW, TILE>& L, uint32_t (&key)[TILE / NW / 64],
                                              uint32_t (&val)[TILE / NW / 64], const int tile, K* __restrict__ keys_out,
                                              uint32_t* __restrict__ vals_out, const int n, const int shift,
                                              const int nbits, const uint32_t* __restrict__ counts,
                                              const uint32_t* __restrict__ chunk_base,
-                                             const uint32_t* __restrict__ digit_total, uint32_t* __restrict__ status) {
+                                             const uint32_t* __restrict__ digit_total, uint32_t* __restrict__ status,
+                                             uint32_t* __restrict__ key_count = nullptr) {
   constexpr int NT = 64 * NW, WTILE = TILE / NW, NSTEP = WTILE / 64;
   auto& wcnt = L.wcnt;
   auto& gdelta = L.gdelta;
@@ -122,6 +129,7 @@ __device__ __forceinline__ void scatter_core(ScatterLds<K, NW, TILE>& L, uint32_
   }
   __syncthreads();
   // per digit (thread = digit): tile-local base (exclusive over digits), per-wave bases, global delta
+  uint32_t my_lbase = 0, my_cnt = 0;  // COUNT: this thread's digit group in the reordered tile
   {
     uint32_t cw[NW], c = 0;
 #pragma unroll
@@ -130,6 +138,8 @@ __device__ __forceinline__ void scatter_core(ScatterLds<K, NW, TILE>& L, uint32_
       c += cw[k];
     }
     const uint32_t lbase = block_excl_scan_256(c, lane, w, wtot);  // barriers inside: every thread calls it
+    my_lbase = lbase;
+    my_cnt = c;
     if (tid < 256) {
     uint32_t run = lbase;
 #pragma unroll
@@ -193,27 +203,47 @@ __device__ __forceinline__ void scatter_core(ScatterLds<K, NW, TILE>& L, uint32_
   // write-out: consecutive local slots of one digit are consecutive in the output
   const size_t tile_base = (size_t)tile * TILE;
   const uint32_t nvalid = (size_t)n - tile_base < (size_t)TILE ? (uint32_t)((size_t)n - tile_base) : TILE;
+  const uint32_t lomask = (1u << shift) - 1u;
 #pragma unroll
   for (int k = 0; k < TILE / NT; k++) {
     const uint32_t p = (uint32_t)(k * NT + tid);
     if (p < nvalid) {
       const uint32_t kk = (uint32_t)lkey[p];
       const uint32_t g = gdelta[(kk >> shift) & mask] + p;
-      keys_out[g] = (K)kk;
+      if (!COUNT) keys_out[g] = (K)kk;
       vals_out[g] = lval[p];
+    }
+  }
+  if (COUNT && tid < 256 && my_cnt) {
+    // thread = digit: its group [my_lbase, my_lbase + my_cnt) of the reordered tile is sorted by the low part (the
+    // pass is stable and its input was sorted by it), which takes very few distinct values inside one tile: count
+    // each by bisection -- no atomics in LDS -- and add it to the key's global counter
+    uint32_t prev = my_lbase;
+    const uint32_t end = my_lbase + my_cnt;
+    while (prev < end) {
+      const uint32_t lo = (uint32_t)lkey[prev] & lomask;  // next distinct low part of this group
+      uint32_t a = prev + 1, b = end;                     // first index with a larger low part
+      while (a < b) {
+        const uint32_t m = (a + b) >> 1;
+        if (((uint32_t)lkey[m] & lomask) <= lo) a = m + 1; else b = m;
+      }
+      const uint32_t kk = ((uint32_t)tid << shift) | lo;
+      (void)__hip_atomic_fetch_add(key_count + 2 * (size_t)kk + 1, a - prev, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      prev = a;
     }
   }
 }
 
 
-template <typename K, bool LB, bool ARANK, int NW, int TILE>
+template <typename K, bool LB, bool ARANK, int NW, int TILE, bool COUNT = false>
 __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ keys_in,
                                                       const uint32_t* __restrict__ vals_in,
                                                       K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                       int n, int shift, int nbits, const uint32_t* __restrict__ counts,
                                                       const uint32_t* __restrict__ chunk_base,
                                                       const uint32_t* __restrict__ digit_total,
-                                                      uint32_t* __restrict__ status, uint32_t* __restrict__ ticket) {
+                                                      uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
+                                                      uint32_t* __restrict__ key_count = nullptr) {
   constexpr int WTILE = TILE / NW, NSTEP = WTILE / 64;
   __shared__ ScatterLds<K, NW, TILE> L;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -233,8 +263,8 @@ __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ 
     key[s] = valid ? (uint32_t)keys_in[i] : 0u;
     val[s] = valid ? vals_in[i] : 0u;
   }
-  scatter_core<K, LB, ARANK, NW, TILE>(L, key, val, tile, keys_out, vals_out, n, shift, nbits, counts, chunk_base,
-                                       digit_total, status);
+  scatter_core<K, LB, ARANK, NW, TILE, COUNT>(L, key, val, tile, keys_out, vals_out, n, shift, nbits, counts, chunk_base,
+                                              digit_total, status, key_count);
 }
 
 }  // namespace gsr
