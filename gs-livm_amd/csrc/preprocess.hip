@@ -1,10 +1,12 @@
 // preprocess.hip -- per-Gaussian and per-instance bookkeeping stages of the MI355X rasterizer (gfx950):
 //   F1  k_preprocess        project / cull / EWA / SH->RGB, footprint-box tile rectangle, 48-B splat record,
-//                           depth-sort pair; publishes num_rendered to the host mailbox (last workgroup)
-//   F3  k_scan_offsets      single-launch (look-back) scan of the tile counts in depth order; descriptors gathered
-//                           into depth order, slotinfo, emission chunk table
-//   F4  k_emit              output-centric emission of (tile id, Gaussian id) pairs in depth order (+ the digit
-//                           counts of the sort's first pass)
+//                           depth-sort pair + the depth sort's digit histograms; publishes num_rendered to the
+//                           host mailbox (last workgroup)
+//   F3  k_scan_offsets      single-launch (look-back) scan of the tile counts in depth order; 16-byte emission
+//                           descriptors in depth order, slotinfo, emission chunk table
+//   F4  k_emit              output-centric emission of (tile id, Gaussian id) pairs in depth order; with 16-bit
+//                           tile ids it only counts the digits of the sort's first pass, and
+//       k_emit_scatter      generates the pairs inside that pass (they never reach HBM unsorted)
 //   B2a k_compact_touched / k_gather_records   per-Gaussian sums of the per-instance gradient records (no atomics,
 //                           fixed order)
 //   B2b k_gaussian_backward EWA / projection / SH / covariance chain rule

@@ -17,7 +17,9 @@
 //   * the tile is then REORDERED IN LDS by digit and written out run by run, so global stores are coalesced
 //     runs instead of 64 scattered dwords per instruction.
 // Instance (tile-id) sort, R ~ 10^7 pairs, u16 keys: classic passes -- per-tile digit counts (from k_emit for
-//   the first pass, k_sort_hist after that), k_sort_scan_chunks / k_sort_scan_top, k_sort_scatter.
+//   the first pass, k_sort_hist after that), k_sort_scan_chunks / k_sort_scan_top, k_sort_scatter; the first pass
+//   generates its pairs in place (k_emit_scatter, preprocess.hip), the last one leaves per-tile counts instead of
+//   sorted keys (COUNT, sort_core.hpp) from which k_ranges_from_counts makes the tile ranges.
 // Depth sort, P ~ 10^6 pairs, u32 keys: digit histograms from the key producer (or k_sort_hist_all) and ONE launch
 //   per pass with decoupled look-back (LB): ticketed tiles, one status word per (tile, digit), counts published
 //   right after the key load.  For the 10^7-pair sort the look-back measured slower than the helper kernels
@@ -303,7 +305,7 @@ hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
 }
 
 // Replaces identifyTileRanges (reference rasterizer_impl.cu:106-125); ranges must be zero beforehand (the
-// reference's cudaMemset at :311 -- here a side job of k_sorted_offsets).  Every thread owns 16 bytes of sorted
+// reference's cudaMemset at :311 -- here a side job of k_scan_offsets).  Every thread owns 16 bytes of sorted
 // keys (8 x u16 or 4 x u32) plus the key before them, so the pass over the keys runs at streaming rate.
 template <typename K>
 __global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys, int L, uint2* __restrict__ ranges) {
