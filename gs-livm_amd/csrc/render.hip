@@ -386,27 +386,24 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         const float Graw = __expf(power);
         const float araw = fminf(0.99f, b.y * Graw);
         const bool ok = (pos < lastc) && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
+        // Branch-free per lane: a lane that does not take this splat runs the same code with alpha = 0 and G = 0.
+        // Every gradient term carries a factor alpha or G, so its partials are exact zeros, and the recurrence state
+        // is left untouched bit for bit (accum + 0 * d = accum, T * rcp(1 - 0) = T) -- identical to not having
+        // visited, without the save/restore traffic a divergent `if (ok)` costs.  The state update itself sits
+        // OUTSIDE the wave-uniform "any lane takes it" branch below: inside it the compiler routes the five state
+        // registers through copies at the loop join (5-10 v_mov per visit); as straight-line code they are updated
+        // in place.
+        const float alpha = ok ? araw : 0.0f;
+        const float oma = 1.0f - alpha;
+        const float rom = __builtin_amdgcn_rcpf(oma);
+        const float Tn = T * rom;  // T / (1 - alpha)
+        const float d0 = b.z - ar0, d1 = b.w - ar1, d2 = blue - ar2, da = 1.0f - aacc;
         if (__ballot(ok) != 0ull) {
-          // Branch-free per lane: a lane that does not take this splat runs the same code with alpha = 0 and
-          // G = 0.  Every gradient term carries a factor alpha or G, so its partials are exact zeros, and the
-          // recurrence state is left untouched bit for bit (accum' = 0*c + 1*accum = accum, T * rcp(1 - 0) = T)
-          // -- identical to not having visited, without the save/restore traffic a divergent `if (ok)` costs.
-          const float alpha = ok ? araw : 0.0f;
           const float G = ok ? Graw : 0.0f;
-          const float oma = 1.0f - alpha;
-          const float rom = __builtin_amdgcn_rcpf(oma);
-          T = T * rom;  // T / (1 - alpha)
-          const float dch = alpha * T;
-          float dL_dalpha = (b.z - ar0) * dp0 + (b.w - ar1) * dp1 + (blue - ar2) * dp2 + (1.0f - aacc) * dacc;
-          dL_dalpha *= T;
+          const float dch = alpha * Tn;
+          float dL_dalpha = d0 * dp0 + d1 * dp1 + d2 * dp2 + da * dacc;
+          dL_dalpha *= Tn;
           dL_dalpha += rom * neg_Tf_bg;
-          // Fold this splat into the "everything behind the next one" accumulators NOW: the reference does the
-          // same update at the top of its next iteration from saved (last_alpha, last_color) (backward.cu:533-543);
-          // same operands, same expression, five fewer live registers and no state copies at the loop join.
-          ar0 = __builtin_fmaf(oma, ar0, alpha * b.z);
-          ar1 = __builtin_fmaf(oma, ar1, alpha * b.w);
-          ar2 = __builtin_fmaf(oma, ar2, alpha * blue);
-          aacc = __builtin_fmaf(oma, aacc, alpha);
           // Factors common to every pixel of the splat (opacity, -0.5, 0.5*W, 0.5*H) are applied once per
           // instance when the four quads are combined, not per pixel.
           const float dLG = G * dL_dalpha;  // dL/dG up to the opacity factor; also the opacity partial itself
@@ -428,6 +425,15 @@ __global__ __launch_bounds__(256) void k_blend_backward(
           *reinterpret_cast<float2*>(my_pair + 12u * (uint32_t)jj) = make_float2(0.f, 0.f);
           my_row[12u * (uint32_t)jj] = 0.f;
         }
+        // Fold this splat into the "everything behind the next one" accumulators NOW (the reference does it at the
+        // top of its next iteration from saved (last_alpha, last_color), backward.cu:533-543), in the form
+        // accum + alpha (c - accum) == alpha c + (1 - alpha) accum: the differences are the ones dL_dalpha used and
+        // each update is one in-place fma.
+        T = Tn;
+        ar0 = __builtin_fmaf(alpha, d0, ar0);
+        ar1 = __builtin_fmaf(alpha, d1, ar1);
+        ar2 = __builtin_fmaf(alpha, d2, ar2);
+        aacc = __builtin_fmaf(alpha, da, aacc);
       }
     }
     __syncthreads();
