@@ -323,8 +323,6 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   const float ddelx_dx = 0.5f * (float)fp.W, ddely_dy = 0.5f * (float)fp.H;
   float T = T_final;
   float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, aacc = 0.f;  // accum_rec, accum_acc_rec
-  // entries at or beyond the quad's own last contributor cannot receive gradient from this wave
-  const int quad_last = (int)(w == 0 ? ql0 : w == 1 ? ql1 : w == 2 ? ql2 : ql3);
 
   // this lane's pair slot (first 8 floats) and row slot (last 4) inside an entry's 12 floats
   float* const my_pair = &sPart[w][0][0] + 2 * (lane >> 4);
@@ -355,6 +353,9 @@ __global__ __launch_bounds__(256) void k_blend_backward(
               !ellipse_reaches_quad(a.x, a.y, a.z, a.w, b.x, tau, tx0 + (float)((q & 1) * 8), ty0 + (float)((q >> 1) * 8)))
             hits &= ~(1u << q);
       }
+      // entries at or beyond a quad's own last contributor cannot receive gradient from that quad
+      hits &= (pos < (int)ql0 ? 1u : 0u) | (pos < (int)ql1 ? 2u : 0u) | (pos < (int)ql2 ? 4u : 0u) |
+              (pos < (int)ql3 ? 8u : 0u);
     }
     if (w < LW) {
 #pragma unroll
@@ -371,13 +372,6 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         m &= m - 1;
         const int jj = lw * 64 + bpos;
         const int pos = n - 1 - (base + jj);  // 0-based index in the tile list == `contributor` after decrement
-        if (pos >= quad_last) {                // wave-uniform: nothing to do for this quad, publish zeros
-          if ((lane & 15) == 0) {
-            *reinterpret_cast<float2*>(my_pair + 12u * (uint32_t)jj) = make_float2(0.f, 0.f);
-            my_row[12u * (uint32_t)jj] = 0.f;
-          }
-          continue;
-        }
         const float4 a = sE[jj][0];
         const float4 b = sE[jj][1];
         const float blue = sE[jj][2].x;
