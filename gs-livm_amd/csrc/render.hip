@@ -291,7 +291,8 @@ __global__ __launch_bounds__(256) void k_blend_backward(
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dacc, float4* __restrict__ grad_inst,
     uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched) {
   constexpr int LW = BCHUNK / 64;  // loader waves
-  // one 48-byte image per staged entry -- (x, y, conic.x, conic.y | conic.z, opacity, r, g | b, -, -, -) -- so a visit
+  // one 48-byte image per staged entry -- (x, y, conic.x', conic.y' | conic.z', opacity, r, g | b, conic) with the
+  // primed terms pre-scaled for exp2 -- so a visit
   // addresses all of it from ONE register (base + 48 jj) with immediate offsets
   __shared__ float4 sE[BCHUNK][3];
   __shared__ uint32_t sSlot[BCHUNK], sId[BCHUNK];
@@ -339,9 +340,12 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       const float4 c = splats[(size_t)id * SPLAT_F4 + 2];
       const uint2 si = slotinfo[id];
       const int x0 = (int)(si.y & 1023u), y0 = (int)((si.y >> 10) & 1023u), rw = (int)(si.y >> 20);
-      sE[tid][0] = a;
-      sE[tid][1] = b;
-      sE[tid][2] = make_float4(c.x, 0.f, 0.f, 0.f);
+      // the visits read the conic pre-scaled (power's -1/2 and the log2(e) of exp(x) = exp2(x log2 e): one multiply per
+      // ENTRY here instead of two instructions per visit); the combine step reads the plain conic from the third slot
+      constexpr float L2E = 1.4426950408889634f;
+      sE[tid][0] = make_float4(a.x, a.y, a.z * (-0.5f * L2E), a.w * (-L2E));
+      sE[tid][1] = make_float4(b.x * (-0.5f * L2E), b.y, b.z, b.w);
+      sE[tid][2] = make_float4(c.x, a.z, a.w, b.x);
       sId[tid] = id;
       sSlot[tid] = si.x + (uint32_t)(((int)blockIdx.y - y0) * rw + ((int)blockIdx.x - x0));
       hits = quad_hits(a.x, a.y, c.z, c.w, tx0, ty0);
@@ -376,8 +380,8 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         const float4 b = sE[jj][1];
         const float blue = sE[jj][2].x;
         const float dx = a.x - pfx, dy = a.y - pfy;
-        const float power = -0.5f * (a.z * dx * dx + b.x * dy * dy) - a.w * dx * dy;
-        const float Graw = __expf(power);
+        const float power = a.z * (dx * dx) + b.x * (dy * dy) + a.w * (dx * dy);  // = log2(e) x the reference's power
+        const float Graw = __builtin_amdgcn_exp2f(power);
         const float araw = fminf(0.99f, b.y * Graw);
         const bool ok = (pos < lastc) && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
         // Branch-free per lane: a lane that does not take this splat runs the same code with alpha = 0 and G = 0.
@@ -411,6 +415,9 @@ __global__ __launch_bounds__(256) void k_blend_backward(
           float w0, w1;
           wave_sum8(g0, g1, g2, g3, g4, g5, g6, g7, w0, w1);
           g8 = row_allsum(g8);
+          // pin the sums here: otherwise the compiler sinks the last add of each tree into the 4-lane store block
+          // below and leaves a v_mov_dpp + v_add pair where one v_add_dpp does (3 instructions per visit)
+          asm volatile("" : "+v"(w0), "+v"(w1), "+v"(g8));
           if ((lane & 15) == 0) {  // lanes 0,16,32,48 hold the totals of (g0,g1),(g2,g3),(g4,g5),(g6,g7)
             *reinterpret_cast<float2*>(my_pair + 12u * (uint32_t)jj) = make_float2(w0, w1);
             my_row[12u * (uint32_t)jj] = g8;  // this row's share of the opacity partial
@@ -447,12 +454,11 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       }
       if (any) {
         const size_t slot = sSlot[tid];
-        const float4 ca = sE[tid][0];
-        const float4 cb = sE[tid][1];
-        const float op = cb.y;  // dL/dG = opacity * dL/dalpha; conic terms carry -0.5 (backward.cu:583-597)
+        const float4 cc = sE[tid][2];  // (blue, conic.x, conic.y, conic.z): the plain conic
+        const float op = sE[tid][1].y;  // dL/dG = opacity * dL/dalpha; conic terms carry -0.5 (backward.cu:583-597)
         const float mx = op * ddelx_dx, my = op * ddely_dy, mc = -0.5f * op;
-        const float gx = -(ca.z * s[3] + ca.w * s[4]);  // dG_ddelx, dG_ddely summed over the pixels (backward.cu:561-562)
-        const float gy = -(cb.x * s[4] + ca.w * s[3]);
+        const float gx = -(cc.y * s[3] + cc.z * s[4]);  // dG_ddelx, dG_ddely summed over the pixels (backward.cu:561-562)
+        const float gy = -(cc.w * s[4] + cc.z * s[3]);
         grad_inst[slot * GRAD_F4 + 0] = make_float4(s[0], s[1], s[2], gx * mx);
         grad_inst[slot * GRAD_F4 + 1] = make_float4(gy * my, s[5] * mc, s[6] * mc, s[7] * mc);
         grad_inst[slot * GRAD_F4 + 2] = make_float4(s[8], 0.f, 0.f, 0.f);
