@@ -297,9 +297,10 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   __shared__ float4 sE[BCHUNK][3];
   __shared__ uint32_t sSlot[BCHUNK], sId[BCHUNK];
   __shared__ uint64_t smask[4][LW];
-  // per (quad, entry): 8 wave totals (four 8-B pairs) + the FOUR 16-lane-row partials of the ninth value: the
-  // rows are added in the combine step (once per instance) instead of two more cross-lane steps per visit
-  __shared__ __attribute__((aligned(8))) float sPart[4][BCHUNK][12];
+  // per (quad, entry): four (pair of wave totals, 16-lane-row partial of the ninth value) triples, one per row of the
+  // wave: the row partials are added in the combine step (once per instance) instead of two more cross-lane steps
+  // per visit
+  __shared__ __attribute__((aligned(16))) float sPart[4][BCHUNK][12];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tile = blockIdx.y * fp.gx + blockIdx.x;
   const uint32_t ql0 = quad_last_in[4 * tile], ql1 = quad_last_in[4 * tile + 1], ql2 = quad_last_in[4 * tile + 2],
@@ -323,11 +324,13 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   const float neg_Tf_bg = -T_final * bg_dot;  // per-pixel constant of the background term (backward.cu:578-581)
   const float ddelx_dx = 0.5f * (float)fp.W, ddely_dy = 0.5f * (float)fp.H;
   float T = T_final;
-  float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f, aacc = 0.f;  // accum_rec, accum_acc_rec
+  float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;  // accum_rec
+  float nacc = 1.0f;                      // 1 - accum_acc_rec: the form dL_dalpha uses; its update is one multiply
 
   // this lane's pair slot (first 8 floats) and row slot (last 4) inside an entry's 12 floats
-  float* const my_pair = &sPart[w][0][0] + 2 * (lane >> 4);
-  float* const my_row = &sPart[w][0][0] + 8 + (lane >> 4);
+  // (row r of the wave owns floats [3r, 3r + 2]: its pair of wave totals and its share of the ninth value -- one
+  // 12-byte store per visit from one address register)
+  float* const my_part = &sPart[w][0][0] + 3 * (lane >> 4);
   for (int base = 0; base < n; base += BCHUNK) {
     const int k = base + tid;  // k-th entry counted from the back of [0, n)
     const bool stager = tid < BCHUNK;
@@ -395,7 +398,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         const float oma = 1.0f - alpha;
         const float rom = __builtin_amdgcn_rcpf(oma);
         const float Tn = T * rom;  // T / (1 - alpha)
-        const float d0 = b.z - ar0, d1 = b.w - ar1, d2 = blue - ar2, da = 1.0f - aacc;
+        const float d0 = b.z - ar0, d1 = b.w - ar1, d2 = blue - ar2, da = nacc;
         if (__ballot(ok) != 0ull) {
           const float G = ok ? Graw : 0.0f;
           const float dch = alpha * Tn;
@@ -419,12 +422,12 @@ __global__ __launch_bounds__(256) void k_blend_backward(
           // below and leaves a v_mov_dpp + v_add pair where one v_add_dpp does (3 instructions per visit)
           asm volatile("" : "+v"(w0), "+v"(w1), "+v"(g8));
           if ((lane & 15) == 0) {  // lanes 0,16,32,48 hold the totals of (g0,g1),(g2,g3),(g4,g5),(g6,g7)
-            *reinterpret_cast<float2*>(my_pair + 12u * (uint32_t)jj) = make_float2(w0, w1);
-            my_row[12u * (uint32_t)jj] = g8;  // this row's share of the opacity partial
+            float* const dst = my_part + 12u * (uint32_t)jj;  // (w0, w1, this row's share of the opacity partial)
+            dst[0] = w0; dst[1] = w1; dst[2] = g8;
           }
         } else if ((lane & 15) == 0) {
-          *reinterpret_cast<float2*>(my_pair + 12u * (uint32_t)jj) = make_float2(0.f, 0.f);
-          my_row[12u * (uint32_t)jj] = 0.f;
+          float* const dst = my_part + 12u * (uint32_t)jj;
+          dst[0] = 0.f; dst[1] = 0.f; dst[2] = 0.f;
         }
         // Fold this splat into the "everything behind the next one" accumulators NOW (the reference does it at the
         // top of its next iteration from saved (last_alpha, last_color), backward.cu:533-543), in the form
@@ -434,7 +437,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         ar0 = __builtin_fmaf(alpha, d0, ar0);
         ar1 = __builtin_fmaf(alpha, d1, ar1);
         ar2 = __builtin_fmaf(alpha, d2, ar2);
-        aacc = __builtin_fmaf(alpha, da, aacc);
+        nacc = nacc * oma;  // 1 - (acc + alpha (1 - acc)) = (1 - acc)(1 - alpha)
       }
     }
     __syncthreads();
@@ -448,8 +451,11 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         if ((smask[q][lw] >> (tid & 63)) & 1ull) {
           any = true;
 #pragma unroll
-          for (int t = 0; t < 8; t++) s[t] += sPart[q][tid][t];
-          s[8] += (sPart[q][tid][8] + sPart[q][tid][9]) + (sPart[q][tid][10] + sPart[q][tid][11]);
+          for (int r = 0; r < 4; r++) {  // row r carries the wave totals of values 2r, 2r + 1
+            s[2 * r] += sPart[q][tid][3 * r];
+            s[2 * r + 1] += sPart[q][tid][3 * r + 1];
+          }
+          s[8] += (sPart[q][tid][2] + sPart[q][tid][5]) + (sPart[q][tid][8] + sPart[q][tid][11]);
         }
       }
       if (any) {
