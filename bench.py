@@ -364,6 +364,8 @@ def main():
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in d.items()}
                     for k, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         "workload_stats": stats,
+        # forwards whose instance count reached the host through the fallback stream query (0 in a healthy run)
+        "mailbox_slow_path_hits": int(G.lib().gsr_mailbox_slow_path_hits()),
         # SURVEY.md 8(d) work units: instances through the binning per second of step time, and (pixel, contributor)
         # pairs per second of each blend kernel's own time (contributors = n_contrib summed over the image)
         "work_units": {

@@ -34,7 +34,7 @@ _lib = None
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_bytes", "gsr_image_bytes",
            "gsr_binning_bytes", "gsr_geometry_view_of", "gsr_binning_view_of", "gsr_image_view_of",
            "gsr_higher_msb", "gsr_last_error", "gsr_abi_version", "gsr_kernel_count", "gsr_kernel_name",
-           "gsr_profile_enable", "gsr_profile_enable_only", "gsr_profile_read", "gsr_activate", "gsr_activate_backward", "gsr_adam_step",
+           "gsr_profile_enable", "gsr_profile_enable_only", "gsr_profile_read", "gsr_mailbox_slow_path_hits", "gsr_activate", "gsr_activate_backward", "gsr_adam_step",
            "gsr_photometric_loss", "gsr_photometric_loss_workspace", "gsr_init_gaussians", "gsr_ply_row_floats",
            "gsr_pack_ply_rows", "gsr_model_step")
 
@@ -75,6 +75,8 @@ def lib():
     L.gsr_kernel_name.argtypes = [ci]
     L.gsr_profile_enable.argtypes = [ci]
     L.gsr_profile_enable_only.argtypes = [C.POINTER(ci), ci]
+    L.gsr_mailbox_slow_path_hits.restype = C.c_ulonglong
+    L.gsr_mailbox_slow_path_hits.argtypes = []
     L.gsr_profile_read.restype = ci
     L.gsr_profile_read.argtypes = [ci, C.POINTER(C.c_double), C.POINTER(ci)]
     L.gsr_activate.restype = ci

@@ -1155,8 +1155,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float* 
 }
 
 // ---------------------------------- launchers ----------------------------------------------------
-// whether k_preprocess counts the depth sort's digit histograms for this call (not in the LDS-staged SH variant)
+// whether k_preprocess counts the depth sort's digit histograms for this call: not in the LDS-staged SH variant,
+// and only when its workgroups walk several blocks each (beyond 1 M Gaussians) -- every workgroup flushes ~770
+// bins with global atomics, which a one-block workgroup cannot hide (500 k Gaussians: 29 -> 51 us, against 10 us
+// for the sort's own histogram pass)
 bool preprocess_counts_depth_digits(const FrameParams& fp, const float* shs, const float* colors_precomp) {
+  if (fp.P <= (1 << 20)) return false;
   return !((shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0);
 }
 
