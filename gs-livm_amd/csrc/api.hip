@@ -241,12 +241,12 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   {
     using clk = std::chrono::steady_clock;
     const clk::time_point t0 = t_enqueued;
-    // Safety net: stream queries from 100 us on, every 50 us.  Seen on this pool (2 of ~60 bench processes): the
+    // Safety net: stream queries from 60 us on, every 25 us.  Seen on this pool (2 of ~60 bench processes): the
     // word never becomes visible to the spinning load and only the query path below returns -- with a 2 ms period
-    // that cost 1.3 ms of GPU idle per forward, with 50 us it costs at most the tail of one period after the
+    // that cost 1.3 ms of GPU idle per forward, with 25 us it costs at most the tail of one period after the
     // stream has drained.  (gsr_mailbox_slow_path_hits() counts these exits; bench.py reports it.)
-    const auto query_period = std::chrono::microseconds(50);
-    clk::time_point next_query = t0 + std::chrono::microseconds(100);
+    const auto query_period = std::chrono::microseconds(25);
+    clk::time_point next_query = t0 + std::chrono::microseconds(60);
     for (;;) {
       const unsigned long long v = __atomic_load_n(mailbox, __ATOMIC_ACQUIRE);
       if ((uint32_t)(v >> 32) == ticket) { R_host = (uint32_t)v; break; }

@@ -210,7 +210,7 @@ int gsr_profile_enable_only(const int* kernel_ids, int n);
 int gsr_profile_read(int max_ids, double* total_ms, int* launches);
 /* diagnostics: number of gsr_forward calls of this process whose instance count reached the host through the
  * fallback stream query instead of the polled mailbox word (0 in a healthy run; each one leaves the GPU idle for up
- * to one query period, 50 us). */
+ * to one query period, 25 us). */
 unsigned long long gsr_mailbox_slow_path_hits(void);
 
 const char* gsr_last_error(void);
