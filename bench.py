@@ -319,7 +319,11 @@ def main():
         if ent and ent.get("valu_issue_ms"):
             roofline["valu_issue"] = dict(wave_instructions_per_launch=ent["SQ_INSTS_VALU"],
                                           floor_ms=ent["valu_issue_ms"],
-                                          frac_of_launch=round(ent["valu_issue_ms"] / kernels[dom]["avg_launch_ms"], 3))
+                                          frac_of_launch=round(ent["valu_issue_ms"] / kernels[dom]["avg_launch_ms"], 3),
+                                          # launch time in SIMD-cycles (1024 SIMDs x 2.4 GHz) per VALU wave-instruction:
+                                          # 2 = the SIMD-32 issue peak, 4 = what one wave alone sustains
+                                          simd_cycles_per_valu_instruction=round(
+                                              kernels[dom]["avg_launch_ms"] * 1e-3 * 1024 * 2.4e9 / ent["SQ_INSTS_VALU"], 2))
     except (OSError, ValueError):
         pass
     # whole path: sum over kernels of (algorithmic bytes per launch x launches per step)
