@@ -320,6 +320,12 @@ def main():
             roofline["valu_issue"] = dict(wave_instructions_per_launch=ent["SQ_INSTS_VALU"],
                                           floor_ms=ent["valu_issue_ms"],
                                           frac_of_launch=round(ent["valu_issue_ms"] / kernels[dom]["avg_launch_ms"], 3),
+                                          # the same with the rate MEASURED for plain f32 ops at 4-8 waves per SIMD
+                                          # (tools/microbench/valu_rate.hip, profiles/r01n_valu_rate_microbench.txt:
+                                          # v_fma / v_mul 3.0-3.3 cycles, v_add_f32_dpp 4.4-4.7, v_exp 8.3)
+                                          measured_rate_floor_ms=round(ent["SQ_INSTS_VALU"] * 3.0 / (1024 * 2.4e9) * 1e3, 4),
+                                          frac_of_launch_at_measured_rate=round(
+                                              ent["SQ_INSTS_VALU"] * 3.0 / (1024 * 2.4e9) * 1e3 / kernels[dom]["avg_launch_ms"], 3),
                                           # launch time in SIMD-cycles (1024 SIMDs x 2.4 GHz) per VALU wave-instruction:
                                           # 2 = the SIMD-32 issue peak, 4 = what one wave alone sustains
                                           simd_cycles_per_valu_instruction=round(
