@@ -28,6 +28,11 @@ __global__ __launch_bounds__(64) void k_rate(float* out, int iters, float a, flo
         asm volatile("v_mul_f32 %0, %0, %8\n v_mul_f32 %1, %1, %8\n v_mul_f32 %2, %2, %8\n v_mul_f32 %3, %3, %8\n"
                      "v_mul_f32 %4, %4, %8\n v_mul_f32 %5, %5, %8\n v_mul_f32 %6, %6, %8\n v_mul_f32 %7, %7, %8"
                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7) : "v"(a));
+      } else if (KIND == 4) {
+        asm volatile("v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n v_permlane32_swap_b32 %4, %5\n"
+                     "v_permlane32_swap_b32 %6, %7\n v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n"
+                     "v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
       } else {
         asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
                      "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7"
@@ -44,14 +49,14 @@ static void run(const char* name, float* out) {
   for (int W = 1; W <= 8; W *= 2) {
     const int grid = 256 * 4 * W;
     hipEvent_t e0, e1;
-    hipEventCreate(&e0); hipEventCreate(&e1);
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
     hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(64), 0, 0, out, 16, 1.0001f, 0.5f);  // warm-up
-    hipEventRecord(e0, 0);
+    (void)hipEventRecord(e0, 0);
     hipLaunchKernelGGL(k_rate<KIND>, dim3(grid), dim3(64), 0, 0, out, iters, 1.0001f, 0.5f);
-    hipEventRecord(e1, 0);
-    hipEventSynchronize(e1);
+    (void)hipEventRecord(e1, 0);
+    (void)hipEventSynchronize(e1);
     float ms = 0;
-    hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventElapsedTime(&ms, e0, e1);
     const double instr_per_simd = (double)iters * 16 * W;           // wave-instructions issued on one SIMD
     const double cycles = ms * 1e-3 * 2.4e9;                        // at the 2.4 GHz the guide quotes
     printf("%-16s %d wave(s)/SIMD: %.3f ms  -> %.2f cycles per wave-instruction\n", name, W, ms, cycles / instr_per_simd);
@@ -60,11 +65,12 @@ static void run(const char* name, float* out) {
 
 int main() {
   float* out;
-  hipMalloc(&out, 256 * 4 * 8 * 64 * sizeof(float));
+  (void)hipMalloc(&out, 256 * 4 * 8 * 64 * sizeof(float));
   run<0>("v_fma_f32", out);
   run<2>("v_mul_f32", out);
   run<1>("v_add_f32_dpp", out);
   run<3>("v_exp_f32", out);
-  hipFree(out);
+  run<4>("permlane32_swap", out);
+  (void)hipFree(out);
   return 0;
 }
