@@ -33,6 +33,17 @@ __global__ __launch_bounds__(64) void k_rate(float* out, int iters, float a, flo
                      "v_permlane32_swap_b32 %6, %7\n v_permlane32_swap_b32 %0, %1\n v_permlane32_swap_b32 %2, %3\n"
                      "v_permlane32_swap_b32 %4, %5\n v_permlane32_swap_b32 %6, %7"
                      : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
+      } else if (KIND == 5) {
+        asm volatile("v_cndmask_b32_e64 %0, %0, %8, %9\n v_cndmask_b32_e64 %1, %1, %8, %9\n v_cndmask_b32_e64 %2, %2, %8, %9\n"
+                     "v_cndmask_b32_e64 %3, %3, %8, %9\n v_cndmask_b32_e64 %4, %4, %8, %9\n v_cndmask_b32_e64 %5, %5, %8, %9\n"
+                     "v_cndmask_b32_e64 %6, %6, %8, %9\n v_cndmask_b32_e64 %7, %7, %8, %9"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7)
+                     : "v"(a), "s"(0x5555555555555555ull));
+      } else if (KIND == 6) {
+        asm volatile("v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n v_permlane16_swap_b32 %4, %5\n"
+                     "v_permlane16_swap_b32 %6, %7\n v_permlane16_swap_b32 %0, %1\n v_permlane16_swap_b32 %2, %3\n"
+                     "v_permlane16_swap_b32 %4, %5\n v_permlane16_swap_b32 %6, %7"
+                     : "+v"(x0), "+v"(x1), "+v"(x2), "+v"(x3), "+v"(x4), "+v"(x5), "+v"(x6), "+v"(x7));
       } else {
         asm volatile("v_exp_f32 %0, %0\n v_exp_f32 %1, %1\n v_exp_f32 %2, %2\n v_exp_f32 %3, %3\n"
                      "v_exp_f32 %4, %4\n v_exp_f32 %5, %5\n v_exp_f32 %6, %6\n v_exp_f32 %7, %7"
@@ -71,6 +82,8 @@ int main() {
   run<1>("v_add_f32_dpp", out);
   run<3>("v_exp_f32", out);
   run<4>("permlane32_swap", out);
+  run<6>("permlane16_swap", out);
+  run<5>("v_cndmask_b32", out);
   (void)hipFree(out);
   return 0;
 }
