@@ -36,7 +36,7 @@ EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_byte
            "gsr_higher_msb", "gsr_last_error", "gsr_abi_version", "gsr_kernel_count", "gsr_kernel_name",
            "gsr_profile_enable", "gsr_profile_enable_only", "gsr_profile_read", "gsr_mailbox_slow_path_hits", "gsr_activate", "gsr_activate_backward", "gsr_adam_step",
            "gsr_photometric_loss", "gsr_photometric_loss_workspace", "gsr_init_gaussians", "gsr_ply_row_floats",
-           "gsr_pack_ply_rows", "gsr_model_step")
+           "gsr_pack_ply_rows", "gsr_model_step", "gsr_set_reference_rects", "gsr_reference_rects")
 
 
 def lib():
@@ -75,6 +75,10 @@ def lib():
     L.gsr_kernel_name.argtypes = [ci]
     L.gsr_profile_enable.argtypes = [ci]
     L.gsr_profile_enable_only.argtypes = [C.POINTER(ci), ci]
+    L.gsr_set_reference_rects.restype = ci
+    L.gsr_set_reference_rects.argtypes = [ci]
+    L.gsr_reference_rects.restype = ci
+    L.gsr_reference_rects.argtypes = []
     L.gsr_mailbox_slow_path_hits.restype = C.c_ulonglong
     L.gsr_mailbox_slow_path_hits.argtypes = []
     L.gsr_profile_read.restype = ci
@@ -204,6 +208,17 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
                                   int(bool(debug)), _stream()))
     out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     return out + (dL_dconic,) if return_conic else out
+
+
+def set_reference_rects(on):
+    """Binning mode (include/gsraster.h): True = the reference's full 3-sigma tile squares (auxiliary.h:39-46), so that
+    tiles_touched / num_rendered / point_list / ranges / n_contrib are the reference's own; False (default) = the
+    footprint-culled rectangles.  Returns the previous setting."""
+    return bool(lib().gsr_set_reference_rects(int(bool(on))))
+
+
+def reference_rects():
+    return bool(lib().gsr_reference_rects())
 
 
 def mark_visible(means3D, viewmatrix, projmatrix):

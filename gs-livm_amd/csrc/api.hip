@@ -3,6 +3,7 @@
 // (reference rasterizer_impl.cu:181-342, :346-457); all device work is in the sibling .hip files.
 #include "../../include/gsraster.h"
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -131,6 +132,15 @@ size_t gsr_binning_bytes(int R) {
   return b;
 }
 
+// Binning mode (gsraster.h, gsr_set_reference_rects): process-wide, initialised once from GSR_REFERENCE_RECTS.
+static std::atomic<int>& reference_rects_flag() {
+  static std::atomic<int> flag([] {
+    const char* e = getenv("GSR_REFERENCE_RECTS");
+    return (e && e[0] && e[0] != '0') ? 1 : 0;
+  }());
+  return flag;
+}
+
 static FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float tan_fovy, float scale_mod) {
   FrameParams fp;
   fp.P = P; fp.D = D; fp.M = M; fp.W = W; fp.H = H;
@@ -141,6 +151,7 @@ static FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx
   fp.focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:210-211
   fp.focal_x = W / (2.0f * tan_fovx);
   fp.scale_modifier = scale_mod;
+  fp.ref_rects = reference_rects_flag().load(std::memory_order_relaxed);
   return fp;
 }
 
@@ -307,6 +318,9 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
   return R;
 }
+
+int gsr_set_reference_rects(int on) { return reference_rects_flag().exchange(on != 0 ? 1 : 0); }
+int gsr_reference_rects(void) { return reference_rects_flag().load(); }
 
 unsigned long long gsr_mailbox_slow_path_hits(void) { return g_mailbox_slow_hits; }
 

@@ -203,6 +203,7 @@ struct BinningState {
 struct FrameParams {
   int P, D, M, W, H, gx, gy;
   float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
+  int ref_rects;  // 1 = emit the reference's full 3-sigma tile square (gsr_set_reference_rects), 0 = footprint-culled
 };
 
 // ---- stage launchers (each enqueues on `s`; returns hipGetLastError()) ----

@@ -347,7 +347,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
           // reference skips it pixel by pixel (forward.cu:343-345, backward.cu:476-478), so images and gradients
           // are unchanged while ~30 % of the instances are never emitted, sorted or walked.  radii stays the
           // reference's value.
-          if (hx < 0.0f) {
+          // gsr_set_reference_rects(1) keeps the reference's square as it is: tiles_touched, num_rendered, the sorted
+          // lists, ranges and n_contrib are then the reference's own, bit for bit (auxiliary.h:39-46,
+          // rasterizer_impl.cu:64-125).
+          if (fp.ref_rects) {
+          } else if (hx < 0.0f) {
             x1 = x0;
           } else if (hx < 1e6f) {
             const float lim = 1e6f;

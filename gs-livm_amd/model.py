@@ -226,6 +226,7 @@ class GrowableGaussians(GaussianParameters):
         for name in self._NAMES:
             setattr(self, name, torch.nn.Parameter(self._buf[name][:self.P]))
         self._next_act = None  # the cached activations describe the old row count
+        self._act_grads = None  # ... and so would gradients parked by a backward that ran before the growth
         if self._optimizer is not None:
             self._optimizer.rebind(self)
 

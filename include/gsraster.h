@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define GSR_ABI_VERSION 1
+#define GSR_ABI_VERSION 2
 
 typedef enum gsr_status {
   GSR_OK = 0,
@@ -126,6 +126,21 @@ typedef struct gsr_image_view {
 int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out);
 int gsr_binning_view_of(char* binning_buffer, int R, gsr_binning_view* out);
 int gsr_image_view_of(char* image_buffer, int width, int height, gsr_image_view* out);
+
+/* Binning mode.  The reference emits one (Gaussian, tile) instance for EVERY tile of the square
+ * getRect() puts around the 3-sigma radius (include/gs/cuda_rasterizer/auxiliary.h:39-46,
+ * duplicateWithKeys, src/cuda_rasterizer/rasterizer_impl.cu:64-101) and then skips, pixel by pixel, the
+ * instances whose alpha stays below 1/255 (forward.cu:374-376).
+ *   0 (default): "culled" -- an instance is emitted only where the Gaussian's exact-conservative
+ *      alpha >= 1/255 footprint box overlaps the tile.  Images, radii and gradients are unchanged;
+ *      tiles_touched, num_rendered, the per-tile lists, ranges and n_contrib describe the shorter lists.
+ *   1: "reference" -- getRect's square as it is: tiles_touched, num_rendered, point_list, ranges and
+ *      n_contrib equal the reference's bit for bit (about 1.4x the instances at 2 M Gaussians, 1080p).
+ * Process-wide, read at every gsr_forward (a backward follows the mode its forward ran in: the rectangles
+ * are stored in the blobs); the initial value comes from the environment variable GSR_REFERENCE_RECTS
+ * (unset / "0" = culled).  gsr_set_reference_rects returns the previous value. */
+int gsr_set_reference_rects(int on);
+int gsr_reference_rects(void);
 
 /* getHigherMsb (rasterizer_impl.cu:35-48): number of tile-id bits the sort covers. */
 uint32_t gsr_higher_msb(uint32_t n);

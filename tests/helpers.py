@@ -14,12 +14,18 @@ def to_dev(scene, dev):
     return t
 
 
-def hip_forward(scene, dev, debug=True):
+def hip_forward(scene, dev, debug=True, ref_rects=False):
+    """ref_rects: binning mode of this forward (include/gsraster.h, gsr_set_reference_rects): True = the
+    reference's own tile rectangles, False = the product's default culled ones.  The previous mode is restored."""
     t = to_dev(scene, dev)
-    out = G.rasterize_forward(t["bg"], t["means3D"], t["colors_precomp"], t["opacities"], t["scales"],
-                              t["rotations"], scene.get("scale_modifier", 1.0), t["cov3D_precomp"], t["viewmatrix"],
-                              t["projmatrix"], scene["tanfovx"], scene["tanfovy"], scene["H"], scene["W"], t["shs"],
-                              scene["sh_degree"], t["campos"], False, debug)
+    prev = G.set_reference_rects(ref_rects)
+    try:
+        out = G.rasterize_forward(t["bg"], t["means3D"], t["colors_precomp"], t["opacities"], t["scales"],
+                                  t["rotations"], scene.get("scale_modifier", 1.0), t["cov3D_precomp"],
+                                  t["viewmatrix"], t["projmatrix"], scene["tanfovx"], scene["tanfovy"], scene["H"],
+                                  scene["W"], t["shs"], scene["sh_degree"], t["campos"], False, debug)
+    finally:
+        G.set_reference_rects(prev)
     return t, out
 
 

@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol():
     assert set(names) == set(G._capi.EXPORTS), (names, G._capi.EXPORTS)
     for n in names:
         assert hasattr(L, n), n
-    assert L.gsr_abi_version() == 1
+    assert L.gsr_abi_version() == 2
 
 
 def test_no_cpu_fallback_when_library_missing(monkeypatch, tmp_path):

@@ -76,10 +76,12 @@ def test_fused_adam_matches_torch_adam(gpu_device):
             torch.testing.assert_close(mine.state[b][key], r, rtol=5e-5, atol=1e-5 * float(r.abs().max()))
 
 
-@pytest.mark.parametrize("P,D", [(3000, 1), (3001, 2), (1500, 3)])  # M = 4 / 9 / 16; odd last workgroup at M = 9
+# M = 4 / 9 / 16 (odd last workgroup at M = 9) and M = 1: SH degree 0 is the product's setting (parameters.cuh:39) and
+# the one bench.py times -- k_model_step's sh_direct branch, an exact multiple of the workgroup size and an odd count
+@pytest.mark.parametrize("P,D", [(3000, 1), (3001, 2), (1500, 3), (4096, 0), (4097, 0)])
 def test_one_optimiser_iteration_fused_vs_torch_ops(P, D, gpu_device):
-    """activations -> rasterizer -> backward -> Adam: the fused path and the reference's separate Torch ops end
-    in the same parameters."""
+    """activations -> rasterizer -> backward -> Adam: the fused path and the reference's separate Torch ops
+    (gaussian.cuh:40-54 getters + torch::optim::Adam as configured in gaussian.cu:396-428) end in the same parameters."""
     dev = gpu_device
     W, H = 200, 120
     r = _raw(P, D, dev, seed=9)

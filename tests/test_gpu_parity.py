@@ -3,12 +3,17 @@ the CPU oracle on the same seeded inputs, against the committed golden vectors, 
 BASELINE.json's full sizes -- through size-independent properties.
 
 Tolerances (BASELINE.json north_star): integer / index results bit-exact (radii, tile counts,
-offsets, sort keys, sorted Gaussian ids, tile ranges) -- radii against the reference's definition, the
-per-tile lists against the oracle's `tight` mode, which applies the product's exact-conservative tile
-culling (oracle/gsr_oracle.c, tighten_rect; tests/test_oracle.py proves on the CPU that it leaves every image
-and gradient bit-identical to the reference's rectangles); colour / depth / silhouette <= 1e-4 abs;
+offsets, sort keys, sorted Gaussian ids, tile ranges, n_contrib); colour / depth / silhouette <= 1e-4 abs;
 gradients |d| <= 1e-5 * max|g| + 1e-4 * |g_row|_inf (f32 summation order differs; SURVEY.md Appendix B;
 see helpers.grad_close).
+
+Two binning modes (include/gsraster.h, gsr_set_reference_rects), both tested against the matching oracle frame:
+  "reference"  the library emits getRect's full 3-sigma tile square (auxiliary.h:39-46, rasterizer_impl.cu:64-125):
+               tiles_touched, num_rendered, keys, point_list, RANGES and n_contrib are compared bit for bit with
+               O.forward(sc) -- the reference's own definition -- and with the fw_* fields of the golden fixtures;
+  "culled"     the product's default: instances are emitted only where the alpha >= 1/255 footprint box overlaps the
+               tile; compared with the oracle's `tight` restatement of that rule (oracle/gsr_oracle.c, tighten_rect;
+               tests/test_oracle.py proves on the CPU that it leaves every image and gradient bit-identical).
 
 Fragile pixels: the blend has hard cuts (alpha < 1/255 skip, T < 1e-4 stop).  Where the oracle sees
 such a test decided by less than rounding distance (frame.fragile), a different-but-valid rounding
@@ -84,6 +89,13 @@ def check_forward(sc, fr, fwd, dev, debug=True, max_fragile=5e-3):
     return v
 
 
+MODES = ("reference", "culled")
+
+
+def oracle_forward(sc, mode, **kw):
+    return O.forward(sc, tight=(mode == "culled"), **kw)
+
+
 def masked_grads(W, H, seed, fragile):
     dcol, dacc = S.make_upstream_grads(W, H, seed)
     keep = (fragile == 0).astype(np.float32)
@@ -101,15 +113,17 @@ SCENES = [  # P, W, H, seed, D
 ]
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("P,W,H,seed,D", SCENES)
-def test_forward_backward_parity(P, W, H, seed, D, gpu_device):
+def test_forward_backward_parity(P, W, H, seed, D, mode, gpu_device):
     sc = S.make_scene(P, W, H, seed, sh_degree=D)
-    fr = O.forward(sc, tight=True)   # integer stages with the product's culled tile rectangles
-    fr_ref = O.forward(sc)           # the reference's rectangles: same radii, images and fragile map bit for bit
-    for k in ("radii", "out_color", "out_depth", "out_acc", "final_T", "fragile"):
-        assert np.array_equal(getattr(fr, k), getattr(fr_ref, k)), k
-    assert (fr.tiles_touched <= fr_ref.tiles_touched).all()
-    t, fwd = hip_forward(sc, gpu_device)
+    fr = oracle_forward(sc, mode)
+    if mode == "culled":  # same radii, images and fragile map as the reference's rectangles, bit for bit
+        fr_ref = O.forward(sc)
+        for k in ("radii", "out_color", "out_depth", "out_acc", "final_T", "fragile"):
+            assert np.array_equal(getattr(fr, k), getattr(fr_ref, k)), k
+        assert (fr.tiles_touched <= fr_ref.tiles_touched).all()
+    t, fwd = hip_forward(sc, gpu_device, ref_rects=(mode == "reference"))
     check_forward(sc, fr, fwd, gpu_device)
     dcol, dacc = masked_grads(W, H, seed, fr.fragile)
     O.set_threads(1)
@@ -122,8 +136,9 @@ def test_forward_backward_parity(P, W, H, seed, D, gpu_device):
         assert not got[k].reshape(P, -1)[~vis].any(), k
 
 
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("name", ["oracle_P300_70x50_D3", "oracle_P2000_160x96_D0"])
-def test_against_committed_golden_vectors(name, gpu_device):
+def test_against_committed_golden_vectors(name, mode, gpu_device):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     P, W, H, seed, D, R = [int(x) for x in z["meta"]]
     sc = dict(W=W, H=H, tanfovx=float(z["in_tanfov"][0]), tanfovy=float(z["in_tanfov"][1]), sh_degree=D,
@@ -138,11 +153,12 @@ def test_against_committed_golden_vectors(name, gpu_device):
     for k in z.files:
         if k.startswith("fw_"):
             setattr(fr, k[3:], z[k])
-    for k in z.files:  # integer stages with the product's culled tile rectangles (oracle tight mode)
-        if k.startswith("tw_"):
-            setattr(fr, k[3:], z[k])
-    fr.R = int(z["meta_tight"][0])
-    t, fwd = hip_forward(sc, gpu_device)
+    if mode == "culled":  # integer stages with the product's culled tile rectangles (oracle tight mode)
+        for k in z.files:
+            if k.startswith("tw_"):
+                setattr(fr, k[3:], z[k])
+        fr.R = int(z["meta_tight"][0])
+    t, fwd = hip_forward(sc, gpu_device, ref_rects=(mode == "reference"))
     check_forward(sc, fr, fwd, gpu_device)
     assert not fr.fragile.any()  # the fixtures were chosen without fragile pixels: full-strength gradients
     got = hip_backward(sc, t, fwd, z["dL_dcolor_in"], z["dL_dacc_in"], gpu_device)
@@ -161,9 +177,13 @@ def test_reference_known_answer_through_hip(gpu_device):
     v = G.state_views(fwd[5], fwd[6], fwd[7], 1, fwd[0], 640, 480)
     sp = v["splats"].cpu().numpy()[0]
     assert int(fwd[4][0]) == e["radius"]
-    # the reference emits the whole 5 x 5 tile square of the 33 px radius (25 instances); the product emits the
-    # tiles its alpha >= 1/255 footprint box overlaps (the splat is ~6 x 2.5 px sigma: far fewer)
+    # the reference emits the whole 5 x 5 tile square of the 33 px radius (25 instances); the product's default emits
+    # the tiles its alpha >= 1/255 footprint box overlaps (the splat is ~6 x 2.5 px sigma: far fewer)
     assert fwd[0] == O.forward(sc, tight=True).R <= e["tiles"] == O.forward(sc).R
+    t2, fwd2 = hip_forward(sc, gpu_device, ref_rects=True)
+    v2 = G.state_views(fwd2[5], fwd2[6], fwd2[7], 1, fwd2[0], 640, 480)
+    assert fwd2[0] == e["tiles"] == int(v2["tiles_touched"][0])   # the survey's reference-produced tile count
+    assert torch.equal(fwd2[1], fwd[1]) and torch.equal(fwd2[3], fwd[3])
     assert np.allclose(sp[0:2], e["xy"], atol=1e-4, rtol=0) and np.allclose(sp[2:5], e["conic"], atol=1e-6, rtol=0)
 
 
@@ -192,9 +212,9 @@ def _variant(P=1500, W=200, H=120, seed=13, D=1):
     return S.make_scene(P, W, H, seed, sh_degree=D)
 
 
-def _full_check(sc, dev, seed=13, stress=False):
-    fr = O.forward(sc, tight=True)
-    t, fwd = hip_forward(sc, dev)
+def _full_check(sc, dev, seed=13, stress=False, mode="culled"):
+    fr = oracle_forward(sc, mode)
+    t, fwd = hip_forward(sc, dev, ref_rects=(mode == "reference"))
     check_forward(sc, fr, fwd, dev, max_fragile=2e-2 if stress else 5e-3)  # needles widen the uncertainty windows
     dcol, dacc = masked_grads(sc["W"], sc["H"], seed, fr.fragile)
     O.set_threads(1)
@@ -206,16 +226,18 @@ def _full_check(sc, dev, seed=13, stress=False):
     return fr, got
 
 
-def test_precomputed_colors_path(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_precomputed_colors_path(mode, gpu_device):
     sc = _variant()
     rng = np.random.default_rng(1)
     sc["colors_precomp"] = rng.uniform(0, 1, (1500, 3)).astype(np.float32)
     sc["shs"] = None
-    fr, got = _full_check(sc, gpu_device)
+    fr, got = _full_check(sc, gpu_device, mode=mode)
     assert got["dL_dsh"].size == 0 and np.abs(got["dL_dcolors"]).max() > 0
 
 
-def test_precomputed_cov3d_path(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_precomputed_cov3d_path(mode, gpu_device):
     sc = _variant()
     base = O.forward(sc)
     cov = base.cov3D.copy()
@@ -223,26 +245,29 @@ def test_precomputed_cov3d_path(gpu_device):
     sc["cov3D_precomp"] = cov
     sc["scales"] = None
     sc["rotations"] = None
-    fr, got = _full_check(sc, gpu_device)
+    fr, got = _full_check(sc, gpu_device, mode=mode)
     assert np.abs(got["dL_dcov3D"]).max() > 0 and not got["dL_dscales"].any() and not got["dL_drotations"].any()
 
 
-def test_scale_modifier_and_black_background(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_scale_modifier_and_black_background(mode, gpu_device):
     sc = _variant(seed=14)
     sc["scale_modifier"] = 0.6
     sc["bg"] = np.array([0.0, 0.25, 0.5], np.float32)
-    _full_check(sc, gpu_device, seed=14)
+    _full_check(sc, gpu_device, seed=14, mode=mode)
 
 
-def test_transparent_and_opaque_extremes(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_transparent_and_opaque_extremes(mode, gpu_device):
     sc = _variant(P=800, seed=15)
     sc["opacities"][:200] = 0.003   # < 1/255: can never contribute
     sc["opacities"][200:400] = 1.0  # alpha saturates at 0.99
-    fr, got = _full_check(sc, gpu_device, seed=15)
+    fr, got = _full_check(sc, gpu_device, seed=15, mode=mode)
     assert not got["dL_dopacity"][:200].any()
 
 
-def test_screen_filling_splats_and_long_lists(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_screen_filling_splats_and_long_lists(mode, gpu_device):
     """Few huge splats (hundreds of tiles each) over many small ones: long per-tile lists (> 1 chunk of
     256), early termination, and Gaussians whose rect is clamped at all four image borders."""
     sc = S.make_scene(6000, 320, 200, 16, sh_degree=0)
@@ -251,29 +276,31 @@ def test_screen_filling_splats_and_long_lists(gpu_device):
     sc["scales"][:20] = 0.29
     sc["means3D"][20:, 2] = np.random.default_rng(2).uniform(6.0, 9.0, 5980).astype(np.float32)
     sc["means3D"][20:, :2] = np.random.default_rng(3).uniform(-0.6, 0.6, (5980, 2)).astype(np.float32)
-    fr, _ = _full_check(sc, gpu_device, seed=16)
+    fr, _ = _full_check(sc, gpu_device, seed=16, mode=mode)
     r = fr.ranges.astype(np.int64)
     assert (r[:, 1] - r[:, 0]).max() > 512 and fr.tiles_touched.max() >= 100
 
 
-def test_large_image_many_tile_bits(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_large_image_many_tile_bits(mode, gpu_device):
     """3000x1700: 188 x 107 = 20116 tiles -> 15 tile-id bits (two 8-bit sort passes), rect origins beyond 127,
     partial tiles on both borders."""
     sc = S.make_scene(30_000, 3000, 1700, 18, sh_degree=0)
     O.set_threads(min(O.max_threads(), 16))
-    fr = O.forward(sc, keep_handle=False, tight=True)
-    t, fwd = hip_forward(sc, gpu_device, debug=False)
+    fr = oracle_forward(sc, mode, keep_handle=False)
+    t, fwd = hip_forward(sc, gpu_device, debug=False, ref_rects=(mode == "reference"))
     check_forward(sc, fr, fwd, gpu_device, debug=False)
     assert int(fr.ranges.max()) == fr.R and fr.ranges.shape[0] == 188 * 107
 
 
-def test_huge_image_32bit_tile_keys(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_huge_image_32bit_tile_keys(mode, gpu_device):
     """4112 x 4112: 257 x 257 = 66049 tiles > 65536, so the tile sort runs on 32-bit keys (17 tile-id bits, three
     passes) instead of the 16-bit path every other test takes."""
     sc = S.make_scene(20_000, 4112, 4112, 23, sh_degree=0)
     O.set_threads(min(O.max_threads(), 16))
-    fr = O.forward(sc, keep_handle=False, tight=True)
-    t, fwd = hip_forward(sc, gpu_device, debug=False)
+    fr = oracle_forward(sc, mode, keep_handle=False)
+    t, fwd = hip_forward(sc, gpu_device, debug=False, ref_rects=(mode == "reference"))
     check_forward(sc, fr, fwd, gpu_device, debug=False)
     assert fr.ranges.shape[0] == 257 * 257 and int(fr.ranges.max()) == fr.R
 
@@ -333,14 +360,16 @@ def _random_scenes(rng, ncases, gpu_device):
         sc["scales"] = (sc["scales"] * rng.uniform(0.5, 2.0, (P, 3))).astype(np.float32)      # stronger anisotropy
         sc["rotations"] = (sc["rotations"] * rng.uniform(0.5, 2.0, (P, 1))).astype(np.float32)  # used as given (A.3)
         sc["opacities"] = rng.uniform(0.0, 1.0, (P, 1)).astype(np.float32) ** float(rng.uniform(0.5, 3.0))
-        _full_check(sc, gpu_device, seed=seed, stress=True)
+        for mode in MODES:
+            _full_check(sc, gpu_device, seed=seed, stress=True, mode=mode)
 
 
-def test_tiny_images(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_tiny_images(mode, gpu_device):
     for (W, H) in ((1, 1), (5, 3), (16, 16), (17, 1)):
         sc = S.make_scene(400, W, H, 19, sh_degree=1)
         sc["means3D"][:, :2] *= 0.05  # everything lands on the few pixels there are
-        _full_check(sc, gpu_device, seed=19)
+        _full_check(sc, gpu_device, seed=19, mode=mode)
 
 
 def test_mark_visible(gpu_device):
@@ -567,11 +596,57 @@ def test_c3_determinism_and_backward_linearity(c3, gpu_device):
     assert not A["dL_dmeans3D"][~vis].any() and np.isfinite(A["dL_dmeans3D"]).all()
 
 
-def test_c2_full_parity_with_oracle(gpu_device):
+@pytest.mark.parametrize("mode", MODES)
+def test_c2_full_parity_with_oracle(mode, gpu_device):
     """BASELINE C2 (500 k Gaussians, 1280x720): complete forward parity incl. tile ranges, all threads of the host."""
     P, W, H, seed = S.CONFIGS["C2"]
     sc = S.make_scene(P, W, H, seed)
     O.set_threads(min(O.max_threads(), 16))  # the GPU box's CPU share
-    fr = O.forward(sc, keep_handle=False, tight=True)
-    t, fwd = hip_forward(sc, gpu_device, debug=False)
+    fr = oracle_forward(sc, mode, keep_handle=False)
+    t, fwd = hip_forward(sc, gpu_device, debug=False, ref_rects=(mode == "reference"))
     check_forward(sc, fr, fwd, gpu_device, debug=False)
+
+
+def test_c3_full_parity_with_oracle(c3, gpu_device):
+    """BASELINE C3 at full size (2 M Gaussians, 1920x1080) against the oracle itself, not only through properties:
+    every forward stage in the reference's binning (tiles_touched, num_rendered, keys, point_list, ranges,
+    n_contrib bit-exact against the reference-definition frame), the culled default against the oracle's tight
+    frame, and all nine gradient arrays of the backward."""
+    sc, t_c, fwd_c = c3
+    P, W, H, seed = S.CONFIGS["C3"]
+    O.set_threads(min(O.max_threads(), 16))
+    fr = O.forward(sc)                                   # the reference's definition
+    t, fwd = hip_forward(sc, gpu_device, ref_rects=True)
+    check_forward(sc, fr, fwd, gpu_device)
+    dcol, dacc = masked_grads(W, H, seed, fr.fragile)
+    ref = O.backward(fr, sc, dcol, dacc)
+    got = hip_backward(sc, t, fwd, dcol, dacc, gpu_device, debug=False)
+    for k in GRAD_NAMES:
+        grad_close(got[k], ref[k], k)
+    R_ref = fr.R
+    fr.close()
+    del fr, fwd
+    ft = O.forward(sc, keep_handle=False, tight=True)    # the product's default binning
+    assert ft.R < R_ref
+    check_forward(sc, ft, fwd_c, gpu_device, debug=False)
+    got_c = hip_backward(sc, t_c, fwd_c, dcol, dacc, gpu_device, debug=False)
+    for k in GRAD_NAMES:                                 # same gradients from the shorter lists
+        grad_close(got_c[k], ref[k], k)
+
+
+def test_c4_eight_views_forward_parity(gpu_device):
+    """BASELINE C4's workload on one GPU: the eight keyframe views (yaw offsets C4_YAWS_DEG) of the 2 M-Gaussian scene
+    at 1920x1080, each compared stage by stage with the oracle -- all eight in the reference's binning, the first
+    and the last also in the product's culled default.  (The 8-GPU run shards exactly these views, one per rank.)"""
+    P, W, H, seed = S.CONFIGS["C4"]
+    g = S.make_gaussians(P, seed, aspect=W / H)
+    O.set_threads(min(O.max_threads(), 16))
+    for i, yaw in enumerate(S.C4_YAWS_DEG):
+        sc = dict(g, **S.make_camera(W, H, yaw_deg=yaw), bg=np.ones(3, np.float32), scale_modifier=1.0,
+                  colors_precomp=None, cov3D_precomp=None)
+        for mode in (MODES if i in (0, len(S.C4_YAWS_DEG) - 1) else MODES[:1]):
+            fr = oracle_forward(sc, mode, keep_handle=False)
+            t, fwd = hip_forward(sc, gpu_device, debug=False, ref_rects=(mode == "reference"))
+            check_forward(sc, fr, fwd, gpu_device, debug=False)
+            assert fr.R > 10_000_000
+            del fr, t, fwd
