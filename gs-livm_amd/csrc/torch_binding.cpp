@@ -29,6 +29,16 @@
 
 #include "gsraster.h"
 
+// The declarations this file implements.  In the GS-LIVM tree they are the reference's OWN headers, untouched
+// (-DGSR_REFERENCE_HEADER='"gs/rasterizer.cuh"', which pulls in gs/rasterize_points.cuh); standalone (this repo, the
+// GPU box) the same declarations come from gsr_torch_surface.hpp.  Either way the members below are defined out of
+// line, as strong symbols, exactly where src/gs/rasterizer.cu and src/gs/rasterize_points.cu defined them.
+#ifdef GSR_REFERENCE_HEADER
+#include GSR_REFERENCE_HEADER
+#else
+#include "gsr_torch_surface.hpp"
+#endif
+
 namespace {
 
 void* current_stream() { return static_cast<void*>(c10::hip::getCurrentHIPStream().stream()); }
@@ -147,156 +157,133 @@ torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, tor
   return present;
 }
 
-// ------------------------------- include/gs/gs/rasterizer.cuh ------------------------------------
-struct GaussianRasterizationSettings {
-  int image_height;
-  int image_width;
-  float tanfovx;
-  float tanfovy;
-  torch::Tensor bg;
-  float scale_modifier;
-  torch::Tensor viewmatrix;
-  torch::Tensor projmatrix;
-  int sh_degree;
-  torch::Tensor camera_center;
-  bool prefiltered;
-};
+// ------------------------------- src/gs/rasterizer.cu ---------------------------------------------
+// Out-of-line definitions of the five members include/gs/gs/rasterizer.cuh:22-80 declares without bodies -- the
+// strong symbols render_utils.cuh and lioOptimization.cpp link against once src/gs/rasterizer.cu is gone.
+torch::autograd::tensor_list _RasterizeGaussians::forward(
+    torch::autograd::AutogradContext* ctx, torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh,
+    torch::Tensor colors_precomp, torch::Tensor opacities, torch::Tensor scales, torch::Tensor rotations,
+    torch::Tensor cov3Ds_precomp, torch::Tensor image_height, torch::Tensor image_width, torch::Tensor tanfovx,
+    torch::Tensor tanfovy, torch::Tensor bg, torch::Tensor scale_modifier, torch::Tensor viewmatrix,
+    torch::Tensor projmatrix, torch::Tensor sh_degree, torch::Tensor camera_center, torch::Tensor prefiltered) {
+  // host-resident 0-dim tensors (see rasterize_gaussians below): these reads do not touch the device
+  const int image_height_val = image_height.item<int>();
+  const int image_width_val = image_width.item<int>();
+  const float tanfovx_val = tanfovx.item<float>();
+  const float tanfovy_val = tanfovy.item<float>();
+  const float scale_modifier_val = scale_modifier.item<float>();
+  const int sh_degree_val = sh_degree.item<int>();
+  const bool prefiltered_val = prefiltered.item<bool>();
+  auto [num_rendered, color, out_depth, out_acc, radii, geomBuffer, binningBuffer, imgBuffer] =
+      RasterizeGaussiansCUDA(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier_val,
+                             cov3Ds_precomp, viewmatrix, projmatrix, tanfovx_val, tanfovy_val, image_height_val,
+                             image_width_val, sh, sh_degree_val, camera_center, prefiltered_val, false);
+  ctx->save_for_backward(
+      {colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer});
+  ctx->saved_data["num_rendered"] = num_rendered;
+  ctx->saved_data["background"] = bg;
+  ctx->saved_data["scale_modifier"] = scale_modifier_val;
+  ctx->saved_data["viewmatrix"] = viewmatrix;
+  ctx->saved_data["projmatrix"] = projmatrix;
+  ctx->saved_data["tanfovx"] = tanfovx_val;
+  ctx->saved_data["tanfovy"] = tanfovy_val;
+  ctx->saved_data["image_height"] = image_height_val;
+  ctx->saved_data["image_width"] = image_width_val;
+  ctx->saved_data["sh_degree"] = sh_degree_val;
+  ctx->saved_data["camera_center"] = camera_center;
+  ctx->saved_data["prefiltered"] = prefiltered_val;
+  ctx->mark_non_differentiable({radii});
+  ctx->set_materialize_grads(false);  // no zero images for the outputs nobody differentiates (depth)
+  return {color, radii, out_depth, out_acc};
+}
 
-class _RasterizeGaussians : public torch::autograd::Function<_RasterizeGaussians> {
- public:
-  static torch::autograd::tensor_list forward(
-      torch::autograd::AutogradContext* ctx, torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh,
-      torch::Tensor colors_precomp, torch::Tensor opacities, torch::Tensor scales, torch::Tensor rotations,
-      torch::Tensor cov3Ds_precomp, torch::Tensor image_height, torch::Tensor image_width, torch::Tensor tanfovx,
-      torch::Tensor tanfovy, torch::Tensor bg, torch::Tensor scale_modifier, torch::Tensor viewmatrix,
-      torch::Tensor projmatrix, torch::Tensor sh_degree, torch::Tensor camera_center, torch::Tensor prefiltered) {
-    const int image_height_val = image_height.item<int>();
-    const int image_width_val = image_width.item<int>();
-    const float tanfovx_val = tanfovx.item<float>();
-    const float tanfovy_val = tanfovy.item<float>();
-    const float scale_modifier_val = scale_modifier.item<float>();
-    const int sh_degree_val = sh_degree.item<int>();
-    const bool prefiltered_val = prefiltered.item<bool>();
-    auto [num_rendered, color, out_depth, out_acc, radii, geomBuffer, binningBuffer, imgBuffer] =
-        RasterizeGaussiansCUDA(bg, means3D, colors_precomp, opacities, scales, rotations, scale_modifier_val,
-                               cov3Ds_precomp, viewmatrix, projmatrix, tanfovx_val, tanfovy_val, image_height_val,
-                               image_width_val, sh, sh_degree_val, camera_center, prefiltered_val, false);
-    ctx->save_for_backward(
-        {colors_precomp, means3D, scales, rotations, cov3Ds_precomp, radii, sh, geomBuffer, binningBuffer, imgBuffer});
-    ctx->saved_data["num_rendered"] = num_rendered;
-    ctx->saved_data["background"] = bg;
-    ctx->saved_data["scale_modifier"] = scale_modifier_val;
-    ctx->saved_data["viewmatrix"] = viewmatrix;
-    ctx->saved_data["projmatrix"] = projmatrix;
-    ctx->saved_data["tanfovx"] = tanfovx_val;
-    ctx->saved_data["tanfovy"] = tanfovy_val;
-    ctx->saved_data["image_height"] = image_height_val;
-    ctx->saved_data["image_width"] = image_width_val;
-    ctx->saved_data["sh_degree"] = sh_degree_val;
-    ctx->saved_data["camera_center"] = camera_center;
-    ctx->saved_data["prefiltered"] = prefiltered_val;
-    ctx->mark_non_differentiable({radii});
-    ctx->set_materialize_grads(false);  // no zero images for the outputs nobody differentiates (depth)
-    return {color, radii, out_depth, out_acc};
+torch::autograd::tensor_list _RasterizeGaussians::backward(torch::autograd::AutogradContext* ctx,
+                                                           torch::autograd::tensor_list grad_outputs) {
+  auto grad_out_color = grad_outputs[0];
+  // grad_outputs[1] (radii) and [2] (depth) are ignored, exactly as the reference (rasterizer.cu:78-79)
+  auto grad_acc = grad_outputs[3];
+  const int num_rendered = ctx->saved_data["num_rendered"].to<int>();
+  auto saved = ctx->get_saved_variables();
+  auto colors_precomp = saved[0], means3D = saved[1], scales = saved[2], rotations = saved[3],
+       cov3Ds_precomp = saved[4], radii = saved[5], sh = saved[6], geomBuffer = saved[7], binningBuffer = saved[8],
+       imgBuffer = saved[9];
+  const int H = ctx->saved_data["image_height"].to<int>(), W = ctx->saved_data["image_width"].to<int>();
+  if (!grad_out_color.defined()) grad_out_color = torch::zeros({3, H, W}, means3D.options());
+  if (!grad_acc.defined()) grad_acc = torch::zeros({1, H, W}, means3D.options());
+  auto [grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
+        grad_rotations] =
+      RasterizeGaussiansBackwardCUDA(
+          ctx->saved_data["background"].to<torch::Tensor>(), means3D, radii, colors_precomp, scales, rotations,
+          ctx->saved_data["scale_modifier"].to<double>(), cov3Ds_precomp,
+          ctx->saved_data["viewmatrix"].to<torch::Tensor>(), ctx->saved_data["projmatrix"].to<torch::Tensor>(),
+          ctx->saved_data["tanfovx"].to<double>(), ctx->saved_data["tanfovy"].to<double>(), grad_out_color, grad_acc,
+          sh, ctx->saved_data["sh_degree"].to<int>(), ctx->saved_data["camera_center"].to<torch::Tensor>(),
+          geomBuffer, num_rendered, binningBuffer, imgBuffer, false);
+  auto opt = [](const torch::Tensor& g, const torch::Tensor& x) { return x.numel() ? g : torch::Tensor(); };
+  return {grad_means3D,
+          grad_means2D,
+          opt(grad_sh, sh),
+          opt(grad_colors_precomp, colors_precomp),
+          grad_opacities,
+          opt(grad_scales, scales),
+          opt(grad_rotations, rotations),
+          opt(grad_cov3Ds_precomp, cov3Ds_precomp),
+          torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(),
+          torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
+}
+
+torch::Tensor GaussianRasterizer::mark_visible(torch::Tensor positions) {
+  torch::NoGradGuard no_grad;
+  return markVisible(positions, raster_settings_.viewmatrix, raster_settings_.projmatrix);
+}
+
+torch::autograd::tensor_list GaussianRasterizer::rasterize_gaussians(
+    torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh, torch::Tensor colors_precomp,
+    torch::Tensor opacities, torch::Tensor scales, torch::Tensor rotations, torch::Tensor cov3Ds_precomp,
+    GaussianRasterizationSettings raster_settings) {
+  torch::Device device = means3D.is_cuda() ? means3D.device() : torch::Device(torch::kCUDA);
+  // scalars stay on the host: the reference's 0-dim CUDA tensors cost seven D2H syncs per render
+  auto image_height = torch::tensor(raster_settings.image_height);
+  auto image_width = torch::tensor(raster_settings.image_width);
+  auto tanfovx = torch::tensor(raster_settings.tanfovx);
+  auto tanfovy = torch::tensor(raster_settings.tanfovy);
+  auto scale_modifier = torch::tensor(raster_settings.scale_modifier);
+  auto sh_degree = torch::tensor(raster_settings.sh_degree);
+  auto prefiltered = torch::tensor(raster_settings.prefiltered);
+  auto mv = [&](torch::Tensor t) { return (t.defined() && t.device() != device) ? t.to(device) : t; };
+  return _RasterizeGaussians::apply(mv(means3D), mv(means2D), mv(sh), mv(colors_precomp), mv(opacities), mv(scales),
+                                    mv(rotations), mv(cov3Ds_precomp), image_height, image_width, tanfovx, tanfovy,
+                                    mv(raster_settings.bg), scale_modifier, mv(raster_settings.viewmatrix),
+                                    mv(raster_settings.projmatrix), sh_degree, mv(raster_settings.camera_center),
+                                    prefiltered);
+}
+
+// (the default arguments live on the declaration)
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> GaussianRasterizer::forward(
+    torch::Tensor means3D, torch::Tensor means2D, torch::Tensor opacities, torch::Tensor shs,
+    torch::Tensor colors_precomp, torch::Tensor scales, torch::Tensor rotations, torch::Tensor cov3D_precomp) {
+  if ((shs.defined() && colors_precomp.defined()) || (!shs.defined() && !colors_precomp.defined())) {
+    throw std::invalid_argument("Please provide exactly one of either SHs or precomputed colors!");
   }
-
-  static torch::autograd::tensor_list backward(torch::autograd::AutogradContext* ctx,
-                                               torch::autograd::tensor_list grad_outputs) {
-    auto grad_out_color = grad_outputs[0];
-    // grad_outputs[1] (radii) and [2] (depth) are ignored, exactly as the reference (rasterizer.cu:78-79)
-    auto grad_acc = grad_outputs[3];
-    const int num_rendered = ctx->saved_data["num_rendered"].to<int>();
-    auto saved = ctx->get_saved_variables();
-    auto colors_precomp = saved[0], means3D = saved[1], scales = saved[2], rotations = saved[3],
-         cov3Ds_precomp = saved[4], radii = saved[5], sh = saved[6], geomBuffer = saved[7], binningBuffer = saved[8],
-         imgBuffer = saved[9];
-    const int H = ctx->saved_data["image_height"].to<int>(), W = ctx->saved_data["image_width"].to<int>();
-    if (!grad_out_color.defined()) grad_out_color = torch::zeros({3, H, W}, means3D.options());
-    if (!grad_acc.defined()) grad_acc = torch::zeros({1, H, W}, means3D.options());
-    auto [grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
-          grad_rotations] =
-        RasterizeGaussiansBackwardCUDA(
-            ctx->saved_data["background"].to<torch::Tensor>(), means3D, radii, colors_precomp, scales, rotations,
-            ctx->saved_data["scale_modifier"].to<double>(), cov3Ds_precomp,
-            ctx->saved_data["viewmatrix"].to<torch::Tensor>(), ctx->saved_data["projmatrix"].to<torch::Tensor>(),
-            ctx->saved_data["tanfovx"].to<double>(), ctx->saved_data["tanfovy"].to<double>(), grad_out_color, grad_acc,
-            sh, ctx->saved_data["sh_degree"].to<int>(), ctx->saved_data["camera_center"].to<torch::Tensor>(),
-            geomBuffer, num_rendered, binningBuffer, imgBuffer, false);
-    auto opt = [](const torch::Tensor& g, const torch::Tensor& x) { return x.numel() ? g : torch::Tensor(); };
-    return {grad_means3D,
-            grad_means2D,
-            opt(grad_sh, sh),
-            opt(grad_colors_precomp, colors_precomp),
-            grad_opacities,
-            opt(grad_scales, scales),
-            opt(grad_rotations, rotations),
-            opt(grad_cov3Ds_precomp, cov3Ds_precomp),
-            torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(),
-            torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor(), torch::Tensor()};
+  if (((scales.defined() || rotations.defined()) && cov3D_precomp.defined()) ||
+      (!scales.defined() && !rotations.defined() && !cov3D_precomp.defined())) {
+    throw std::invalid_argument(
+        "Please provide exactly one of either scale/rotation pair or "
+        "precomputed 3D covariance!");
   }
-};
-
-class GaussianRasterizer : torch::nn::Module {
- public:
-  explicit GaussianRasterizer(GaussianRasterizationSettings raster_settings) : raster_settings_(raster_settings) {}
-
-  torch::Tensor mark_visible(torch::Tensor positions) {
-    torch::NoGradGuard no_grad;
-    return markVisible(positions, raster_settings_.viewmatrix, raster_settings_.projmatrix);
+  if ((scales.defined() != rotations.defined()) && !cov3D_precomp.defined()) {
+    throw std::invalid_argument("scales and rotations must be provided together");
   }
-
-  torch::autograd::tensor_list rasterize_gaussians(torch::Tensor means3D, torch::Tensor means2D, torch::Tensor sh,
-                                                   torch::Tensor colors_precomp, torch::Tensor opacities,
-                                                   torch::Tensor scales, torch::Tensor rotations,
-                                                   torch::Tensor cov3Ds_precomp,
-                                                   GaussianRasterizationSettings raster_settings) {
-    torch::Device device = means3D.is_cuda() ? means3D.device() : torch::Device(torch::kCUDA);
-    // scalars stay on the host: the reference's 0-dim CUDA tensors cost seven D2H syncs per render
-    auto image_height = torch::tensor(raster_settings.image_height);
-    auto image_width = torch::tensor(raster_settings.image_width);
-    auto tanfovx = torch::tensor(raster_settings.tanfovx);
-    auto tanfovy = torch::tensor(raster_settings.tanfovy);
-    auto scale_modifier = torch::tensor(raster_settings.scale_modifier);
-    auto sh_degree = torch::tensor(raster_settings.sh_degree);
-    auto prefiltered = torch::tensor(raster_settings.prefiltered);
-    auto mv = [&](torch::Tensor t) { return (t.defined() && t.device() != device) ? t.to(device) : t; };
-    return _RasterizeGaussians::apply(mv(means3D), mv(means2D), mv(sh), mv(colors_precomp), mv(opacities), mv(scales),
-                                      mv(rotations), mv(cov3Ds_precomp), image_height, image_width, tanfovx, tanfovy,
-                                      mv(raster_settings.bg), scale_modifier, mv(raster_settings.viewmatrix),
-                                      mv(raster_settings.projmatrix), sh_degree, mv(raster_settings.camera_center),
-                                      prefiltered);
-  }
-
-  std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor> forward(
-      torch::Tensor means3D, torch::Tensor means2D, torch::Tensor opacities, torch::Tensor shs = torch::Tensor(),
-      torch::Tensor colors_precomp = torch::Tensor(), torch::Tensor scales = torch::Tensor(),
-      torch::Tensor rotations = torch::Tensor(), torch::Tensor cov3D_precomp = torch::Tensor()) {
-    if ((shs.defined() && colors_precomp.defined()) || (!shs.defined() && !colors_precomp.defined())) {
-      throw std::invalid_argument("Please provide exactly one of either SHs or precomputed colors!");
-    }
-    if (((scales.defined() || rotations.defined()) && cov3D_precomp.defined()) ||
-        (!scales.defined() && !rotations.defined() && !cov3D_precomp.defined())) {
-      throw std::invalid_argument(
-          "Please provide exactly one of either scale/rotation pair or "
-          "precomputed 3D covariance!");
-    }
-    if ((scales.defined() != rotations.defined()) && !cov3D_precomp.defined()) {
-      throw std::invalid_argument("scales and rotations must be provided together");
-    }
-    auto empty = [&]() { return torch::empty({0}, means3D.options().dtype(torch::kFloat32)); };
-    if (!shs.defined()) shs = empty();
-    if (!colors_precomp.defined()) colors_precomp = empty();
-    if (!scales.defined()) scales = empty();
-    if (!rotations.defined()) rotations = empty();
-    if (!cov3D_precomp.defined()) cov3D_precomp = empty();
-    auto result = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
-                                      cov3D_precomp, raster_settings_);
-    return {result[0], result[1], result[2], result[3]};
-  }
-
- private:
-  GaussianRasterizationSettings raster_settings_;
-};
+  auto empty = [&]() { return torch::empty({0}, means3D.options().dtype(torch::kFloat32)); };
+  if (!shs.defined()) shs = empty();
+  if (!colors_precomp.defined()) colors_precomp = empty();
+  if (!scales.defined()) scales = empty();
+  if (!rotations.defined()) rotations = empty();
+  if (!cov3D_precomp.defined()) cov3D_precomp = empty();
+  auto result = rasterize_gaussians(means3D, means2D, shs, colors_precomp, opacities, scales, rotations,
+                                    cov3D_precomp, raster_settings_);
+  return {result[0], result[1], result[2], result[3]};
+}
 
 // ------------------------- pybind11 exposure (tests drive the C++ surface) -------------------------
 #ifndef GSR_NO_PYBIND

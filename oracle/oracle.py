@@ -25,6 +25,8 @@ def build_ref():
     """oracle/_ref/check_glm: compiled from the reference's vendored GLM where /root/reference exists (the build
     container); returns its path or None."""
     subprocess.call(["make", "-C", _HERE, "ref"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    # + the link check of the C++ binding against the reference's own headers (oracle/ref_link/; cached)
+    subprocess.call(["make", "-C", _HERE, "ref_link"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
     p = os.path.join(_HERE, "_ref", "check_glm")
     return p if os.path.exists(p) else None
 
