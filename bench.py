@@ -12,17 +12,23 @@ reference's groups / learning rates.  Activations and Adam run as the fused HIP 
 (SURVEY.md 8(f) "next" row 1) unless --torch-optimizer selects the reference's separate Torch ops.
 Inputs are resident in HBM before the timed region.  value = Mpixels/s of the whole job.
 
-N > 1 (launched by torch.distributed.run, one rank per GPU, RCCL): rank r renders view r of the same scene (yaw
-offsets of SURVEY.md 8(d)).  Default --sync-mode scatter = BASELINE config 4 as worded: the flat Gaussian buffer is
-broadcast from rank 0 ONCE before the loop, then every rank runs the full step on its own view with no collective
-per step (the path has no exchange step).  --sync-mode allreduce sums the per-view gradients with one all-reduce of
-the flat gradient buffer (112 MB at M = 1) per step and every rank applies the identical Adam step to its replica
-(SURVEY.md 8(e)); --sync-mode owner = reduce to rank 0 + parameter broadcast.  The rasterizer itself never
-communicates.  scaling = "weak".
+N > 1: one rank per GPU over RCCL, either launched by `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N` (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment) or -- when WORLD_SIZE is not set -- by
+bench.py ITSELF: the parent starts N children before touching the GPU (gs_livm_amd.multiview.launch_local_ranks),
+relays rank 0's JSON line and exits non-zero if any rank fails; `n_gpus` in the line is always the number of ranks
+that really ran.  Rank r renders view r of the same scene (yaw offsets of SURVEY.md 8(d)).  Default --sync-mode scatter
+= BASELINE config 4 as worded: the flat Gaussian buffer is broadcast from rank 0 ONCE before the loop (timed and
+reported as `broadcast_ms`), then every rank runs the full step on its own view with no collective per step (the path
+has no exchange step).  --sync-mode allreduce sums the per-view gradients with one all-reduce of the flat gradient
+buffer (112 MB at M = 1) per step and every rank applies the identical Adam step to its replica (SURVEY.md 8(e));
+--sync-mode owner = reduce to rank 0 + parameter broadcast.  With N > 1 the default run times `scatter` (the headline
+`value`) AND `allreduce` back to back and reports both under "sync_modes" on the one JSON line.  The rasterizer itself
+never communicates.  scaling = "weak".
 
-Extra objects on the JSON line: "roofline" (dominant kernel, algorithmic bytes / hipEvent-measured launch
-time vs 8 TB/s), "cpu_baseline" (the CPU oracle on the same workload, host cores, rank 0 at N = 1 only),
-"kernels" (per-kernel ms per step), "whole_path", "workload_stats" (measured P_vis, R, list lengths) and "work_units".
+Extra objects on the JSON line: "roofline" (dominant kernel: its bound, the live hipEvent-measured launch time over
+the timed region, algorithmic bytes vs 8 TB/s under "hbm", VALU issue rate where the kernel is VALU-bound),
+"cpu_baseline" (the CPU oracle on the same workload, host cores, rank 0 at N = 1 only), "kernels" (per-kernel ms per
+step), "whole_path", "workload_stats" (measured P_vis, R, list lengths) and "work_units".
 """
 import argparse
 import json
@@ -65,7 +71,10 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
         # 16-bit keys: ranges come from the last pass's per-tile counts (scan of T counters), no key read
         "k_tile_ranges": tiles * 16 if kb == 2 else R * kb + tiles * 8,
         "k_sort_scan_chunks": (R // 4096 + 1) * 2048, "k_sort_scan_top": 0,
-        "k_blend_forward": R * 44 + W * H * 28,                   # full lists (early exit reads fewer)
+        # SURVEY.md 8(d)'s 44 B per gathered instance x the entries the kernel has to walk (per tile: up to its last
+        # contributing entry, the same count the backward walks -- NOT the full lists: saturated pixels stop early and
+        # charging 44 R would credit the kernel with bytes it never needs)
+        "k_blend_forward": R_bwd * 44 + W * H * 28,
         "k_blend_backward": W * H * 24 + R_bwd * (40 + 36),       # SURVEY.md 8(d) per-instance figures x walked entries
         "k_compact_touched": P * 1 + P_vis * 0,
         "k_gather_records": R_bwd * 48,
@@ -80,7 +89,10 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
     }
 
 
-def main():
+VALU_PEAK_GINST = 1024 * 2.4 / 2.0  # G wave-instructions/s: 1024 SIMD-32s x 2.4 GHz, one wave64 VALU op per 2 cycles
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -107,13 +119,51 @@ def main():
                          "'allreduce' = joint optimisation of all views: sum the per-view gradients on every rank and "
                          "step replicated Adam (one 56 B/Gaussian collective per step); 'owner' = reduce to rank 0, "
                          "Adam there, broadcast the parameters (two collectives per step)")
+    ap.add_argument("--single-sync-mode", action="store_true",
+                    help="N > 1: time only --sync-mode (default: 'scatter' is followed by an 'allreduce' run, both reported)")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = rehearsal of the multi-rank control flow (collectives staged through the host)")
-    args = ap.parse_args()
+    ap.add_argument("--reference-rects", action="store_true",
+                    help="bin with the reference's full 3-sigma tile squares (gsr_set_reference_rects(1)) instead of the "
+                         "footprint-culled default: the reference's own instance count through the whole path")
+    return ap.parse_args()
+
+
+class _JsonLinesToStdout:
+    """rank 0's stdout as the parent relays it: JSON lines to stdout, anything else (library chatter) to stderr."""
+
+    def write(self, text):
+        for line in text.splitlines():
+            print(line, file=sys.stdout if line.startswith("{") else sys.stderr)
+
+    def flush(self):
+        sys.stdout.flush()
+
+
+def self_launch(args):
+    """--gpus N without an external launcher: N children, one per GPU.  Nothing here may initialise the GPU
+    (torch.cuda.device_count() does not)."""
+    ndev = torch.cuda.device_count()
+    if args.dist_backend == "nccl" and ndev < args.gpus:
+        print("bench.py --gpus %d: only %d GPU(s) visible and RCCL needs one per rank (a rehearsal of the multi-rank "
+              "control flow on fewer GPUs: --dist-backend gloo)" % (args.gpus, ndev), file=sys.stderr)
+        return 2
+    print("[bench] starting %d ranks (one per GPU, backend %s) on 127.0.0.1" % (args.gpus, args.dist_backend),
+          file=sys.stderr)
+    return MV.launch_local_ranks([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], args.gpus,
+                                 out=_JsonLinesToStdout())
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):  # never bench a different rank count than the one asked for
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     local_rank %= max(1, torch.cuda.device_count())  # a gloo rehearsal may put several ranks on one GPU
@@ -127,9 +177,11 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group("gloo", rank=rank, world_size=world)
-    n_gpus = world if world > 1 else 1
-    if args.gpus != n_gpus and rank == 0:
-        print("note: --gpus %d but WORLD_SIZE %d; using %d" % (args.gpus, world, n_gpus), file=sys.stderr)
+        if rank == 0:
+            print("[bench] process group up: backend %s, %d ranks" % (dist.get_backend(), dist.get_world_size()),
+                  file=sys.stderr)
+    n_gpus = world
+    G.set_reference_rects(args.reference_rects)
 
     P, W, H, seed = S.CONFIGS[args.workload]
     D = args.sh_degree
@@ -137,32 +189,9 @@ def main():
     g = S.make_gaussians(P, seed, sh_degree=D, aspect=W / H)
     yaw = S.C4_YAWS_DEG[rank % len(S.C4_YAWS_DEG)] if n_gpus > 1 else 0.0
     cam = S.make_camera(W, H, yaw_deg=yaw)
-
-    # ---- leaf parameters in one flat buffer (the "Gaussian buffer" of BASELINE C4), pre-activation ----
-    params = MV.GaussianBuffer(P, M, dev)
-    grads = MV.GaussianBuffer(P, M, dev)
     pre = dict(means3D=g["means3D"], scales=np.log(g["scales"]), rotations=g["rotations"],
                opacities=np.log(g["opacities"] / (1.0 - g["opacities"])), shs=g["shs"])
-    if rank == 0:
-        params.load({k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in pre.items()})
-    MV.broadcast_gaussians(params, src=0)
-    v = params.views
-    model = G.GaussianParameters(v["means3D"], v["features_dc"], v["features_rest"], v["scales"], v["rotations"],
-                                 v["opacities"])
-    leaves = dict(means3D=model._xyz, features_dc=model._features_dc, features_rest=model._features_rest,
-                  scales=model._scaling, rotations=model._rotation, opacities=model._opacity)
-    joint = n_gpus > 1 and args.sync_mode != "scatter"  # views optimised jointly: gradients are exchanged
-    flat_grads = joint   # one flat gradient buffer = one collective; otherwise autograd hands over its
-    if flat_grads:           # gradient tensors as they are (no accumulate kernels, nothing to zero)
-        for k, p in leaves.items():
-            p.grad = grads.views[k]
-    # groups / learning rates of GaussianModel::Training_setup (src/gs/gaussian.cu:396-428) with the values of
-    # config/basic_common.yaml:54-62, eps 1e-15
-    groups = [gr for gr in model.param_groups() if gr["params"][0].numel()]
-    if args.torch_optimizer:
-        opt = torch.optim.Adam(groups, eps=1e-15, fused=True)
-    else:
-        opt = G.FusedAdam(groups, eps=1e-15)
+    pre = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in pre.items()}
 
     bg = torch.ones(3, device=dev)
     settings = G.GaussianRasterizationSettings(H, W, cam["tanfovx"], cam["tanfovy"], bg, 1.0,
@@ -185,79 +214,124 @@ def main():
     target = torch.rand((3, H, W), generator=torch.Generator().manual_seed(seed)).to(dev)  # --loss photometric
     window = G.reference_window_1d()
 
-    def activated():
-        if args.torch_optimizer:  # the reference's getters as separate Torch ops (gaussian.cuh:40-54)
-            return (model._xyz, torch.sigmoid(model._opacity), torch.exp(model._scaling),
-                    torch.nn.functional.normalize(model._rotation, dim=1),
-                    torch.cat([model._features_dc, model._features_rest], 1))
-        return model.activated()
-
-    owner_mode = joint and args.sync_mode == "owner"
-    tail = not (joint or args.torch_optimizer or args.no_adam or args.no_fused_tail or args.forward_only)
-    model.fused_tail = tail
-
-    def step():
-        if owner_mode:
-            MV.broadcast_gaussians(params, src=0)
-        xyz, op, sc, rot, shs = activated()
-        if args.forward_only:
-            with torch.no_grad():
-                raster(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
-            return
-        color, radii, depth, acc = raster(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
-        means2D.grad = None
-        if args.torch_optimizer and flat_grads:
-            grads.flat.zero_()
-        if args.loss == "photometric":  # lioOptimization.cpp:1705-1710 with lambda_dssim = 0.2
-            G.photometric_loss(color, target, 0.2, window).backward()
-        else:  # upstream gradients injected directly (SURVEY.md 8(d) backward seeds): dL/dcolor = wc, dL/dacc = wa
-            torch.autograd.backward([color, acc], [wc, wa])
-        if joint:
-            MV.reduce_gradients(grads, dst=0, all_ranks=not owner_mode)
-        if tail:
-            opt.step_model(model)
-        elif not args.no_adam and (rank == 0 or not owner_mode):
-            if args.torch_optimizer:
-                opt.step()
-            else:
-                opt.step(zero_grads=flat_grads)  # clears the flat buffer it consumed; replicas stay identical
-        elif flat_grads:
-            grads.flat.zero_()
-        if not flat_grads:
-            for p in leaves.values():
-                p.grad = None
-
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    barrier()
-    # Untimed survey pass: HIP events around EVERY kernel (the `kernels` table).  An event pair costs ~5 us of
-    # GPU idle per launch (~0.2 ms/step over ~45 launches), so the timed region below carries events for the
-    # dominant kernel only -- the one the roofline object is about.
-    G.profile_enable(True)
-    for _ in range(args.steps):
-        step()
-    barrier()
-    G.profile_enable(False)
-    prof = G.profile_read()
-    dom_name = max((k for k, (ms, c) in prof.items() if c), key=lambda k: prof[k][0])
-    G.profile_enable(True, only=[dom_name])
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    G.profile_enable(False)
-    prof_timed = G.profile_read()
-    if dist is not None:
-        tt = torch.tensor([elapsed], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], device=dev if args.dist_backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        return float(tt.item())
+
+    def run_mode(sync_mode, survey):
+        """W warm-up steps, (survey: an untimed pass with hipEvents around every kernel,) then EXACTLY K timed steps
+        between barrier + synchronize pairs; returns the max-over-ranks time and what the stats need."""
+        # ---- leaf parameters in one flat buffer (the "Gaussian buffer" of BASELINE C4), pre-activation ----
+        params = MV.GaussianBuffer(P, M, dev)
+        grads = MV.GaussianBuffer(P, M, dev)
+        if rank == 0:
+            params.load(pre)
+        barrier()
+        t0 = time.perf_counter()
+        MV.broadcast_gaussians(params, src=0)  # C4's one exchange: the shared Gaussian buffer to every GPU
+        barrier()
+        broadcast_ms = max_over_ranks((time.perf_counter() - t0) * 1e3) if dist is not None else None
+        v = params.views
+        model = G.GaussianParameters(v["means3D"], v["features_dc"], v["features_rest"], v["scales"], v["rotations"],
+                                     v["opacities"])
+        leaves = dict(means3D=model._xyz, features_dc=model._features_dc, features_rest=model._features_rest,
+                      scales=model._scaling, rotations=model._rotation, opacities=model._opacity)
+        joint = n_gpus > 1 and sync_mode != "scatter"  # views optimised jointly: gradients are exchanged
+        flat_grads = joint   # one flat gradient buffer = one collective; otherwise autograd hands over its
+        if flat_grads:           # gradient tensors as they are (no accumulate kernels, nothing to zero)
+            for k, p in leaves.items():
+                p.grad = grads.views[k]
+        # groups / learning rates of GaussianModel::Training_setup (src/gs/gaussian.cu:396-428) with the values of
+        # config/basic_common.yaml:54-62, eps 1e-15
+        groups = [gr for gr in model.param_groups() if gr["params"][0].numel()]
+        if args.torch_optimizer:
+            opt = torch.optim.Adam(groups, eps=1e-15, fused=True)
+        else:
+            opt = G.FusedAdam(groups, eps=1e-15)
+
+        def activated():
+            if args.torch_optimizer:  # the reference's getters as separate Torch ops (gaussian.cuh:40-54)
+                return (model._xyz, torch.sigmoid(model._opacity), torch.exp(model._scaling),
+                        torch.nn.functional.normalize(model._rotation, dim=1),
+                        torch.cat([model._features_dc, model._features_rest], 1))
+            return model.activated()
+
+        owner_mode = joint and sync_mode == "owner"
+        tail = not (joint or args.torch_optimizer or args.no_adam or args.no_fused_tail or args.forward_only)
+        model.fused_tail = tail
+
+        def step():
+            if owner_mode:
+                MV.broadcast_gaussians(params, src=0)
+            xyz, op, sc, rot, shs = activated()
+            if args.forward_only:
+                with torch.no_grad():
+                    raster(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
+                return
+            color, radii, depth, acc = raster(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
+            means2D.grad = None
+            if args.torch_optimizer and flat_grads:
+                grads.flat.zero_()
+            if args.loss == "photometric":  # lioOptimization.cpp:1705-1710 with lambda_dssim = 0.2
+                G.photometric_loss(color, target, 0.2, window).backward()
+            else:  # upstream gradients injected directly (SURVEY.md 8(d) backward seeds): dL/dcolor = wc, dL/dacc = wa
+                torch.autograd.backward([color, acc], [wc, wa])
+            if joint:
+                MV.reduce_gradients(grads, dst=0, all_ranks=not owner_mode)
+            if tail:
+                opt.step_model(model)
+            elif not args.no_adam and (rank == 0 or not owner_mode):
+                if args.torch_optimizer:
+                    opt.step()
+                else:
+                    opt.step(zero_grads=flat_grads)  # clears the flat buffer it consumed; replicas stay identical
+            elif flat_grads:
+                grads.flat.zero_()
+            if not flat_grads:
+                for p in leaves.values():
+                    p.grad = None
+
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        prof, dom_name = None, None
+        if survey:
+            # Untimed survey pass: HIP events around EVERY kernel (the `kernels` table).  An event pair costs ~5 us of
+            # GPU idle per launch, so the timed region below carries events for the dominant kernel only -- the one
+            # the roofline object is about.
+            G.profile_enable(True)
+            for _ in range(args.steps):
+                step()
+            barrier()
+            G.profile_enable(False)
+            prof = G.profile_read()
+            dom_name = max((k for k, (ms, c) in prof.items() if c), key=lambda k: prof[k][0])
+            G.profile_enable(True, only=[dom_name])
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = max_over_ranks(time.perf_counter() - t0)
+        prof_timed = None
+        if survey:
+            G.profile_enable(False)
+            prof_timed = G.profile_read()
+        return dict(elapsed=elapsed, prof=prof, prof_timed=prof_timed, dom_name=dom_name, activated=activated,
+                    tail=tail, broadcast_ms=broadcast_ms, collective_bytes_per_step=(
+                        0 if not joint else params.nbytes() * (2 if owner_mode else 1)))
+
+    main_run = run_mode(args.sync_mode, survey=True)
+    elapsed, prof, prof_timed, dom_name = (main_run[k] for k in ("elapsed", "prof", "prof_timed", "dom_name"))
+    activated, tail = main_run["activated"], main_run["tail"]
 
     # ---- workload statistics from one direct forward with the current parameters ----
     with torch.no_grad():
@@ -271,7 +345,7 @@ def main():
         ln = (v["ranges"][:, 1] - v["ranges"][:, 0]).float()
         R_bwd = int(v["quad_last"].long().max(1).values.sum())
         # instance count of the REFERENCE's binning (getRect on the 3-sigma radius, auxiliary.h:46-57) for the same
-        # frame: the footprint-box culling emits fewer; SURVEY.md 8(d)'s whole-path formula is stated on this one
+        # frame: the footprint-box culling emits fewer
         vis = radii > 0
         px, py, rr = v["splats"][vis, 0], v["splats"][vis, 1], radii[vis].float()
         gx, gy = (W + 15) // 16, (H + 15) // 16
@@ -280,9 +354,10 @@ def main():
         R_ref = int(((x1 - x0) * (y1 - y0)).double().sum())
         stats = dict(P=P, P_vis=P_vis, R=R, R_reference_binning=R_ref, R_walked_by_backward=R_bwd, tiles=int(ln.numel()),
                      mean_tile_list=float(ln.mean()), max_tile_list=int(ln.max()),
-                     mean_contrib_per_pixel=float(v["n_contrib"].float().mean()))
+                     mean_contrib_per_pixel=float(v["n_contrib"].float().mean()),
+                     binning="reference rectangles" if args.reference_rects else "footprint-culled (default)")
+        del fw, v
     tiles = stats["tiles"]
-    tile_bits = int(G.lib().gsr_higher_msb(tiles))
     alg = algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles)
     kernels = {}
     for name, (ms, cnt) in prof.items():
@@ -296,54 +371,48 @@ def main():
         ms, cnt = prof_timed[dom]
         kernels[dom].update(ms_per_step=ms / args.steps, avg_launch_ms=ms / cnt,
                             alg_GBps=alg[dom] / (ms / cnt * 1e-3) / 1e9)
-    achieved = alg[dom] / (kernels[dom]["avg_launch_ms"] * 1e-3) / 1e9
-    # HBM bytes per launch of that kernel from the PMC counters (FETCH_SIZE / WRITE_SIZE in separate rocprofv3
-    # passes, corrected as tools/pmc_summary.py documents): PMC collection cannot run inside a timed bench, so the
-    # figure comes from the committed summary of the same command on the same build (profiles/README.md).
-    traffic = None
-    try:
-        with open(os.path.join(ROOT, "profiles", "pmc_traffic_latest.json")) as fh:
-            traffic = json.load(fh).get(dom, {}).get("hbm_bytes_per_launch")
-    except (OSError, ValueError):
-        pass
-    roofline = dict(kernel=dom, bound="hbm", achieved=round(achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=round(achieved / HBM_PEAK_GBS, 4), frac_of_achievable_6300=round(achieved / 6300.0, 4),
-                    traffic=traffic,
-                    algorithmic_bytes_per_launch=int(alg[dom]), avg_launch_ms=round(kernels[dom]["avg_launch_ms"], 4))
-    # Context for a kernel that is not HBM-bound (the blend kernels): its VALU issue floor from the committed SQ
-    # counter summary (tools/sq_summary.py): wave-instructions x 2 cycles / (1024 SIMDs x 2.4 GHz).
-    try:
-        with open(os.path.join(ROOT, "profiles", "sq_counters_latest.json")) as fh:
-            sq = json.load(fh)
-        ent = next((v for k, v in sq.items() if k.split("<")[0] == dom and isinstance(v, dict)), None)
-        if ent and ent.get("valu_issue_ms"):
-            roofline["valu_issue"] = dict(wave_instructions_per_launch=ent["SQ_INSTS_VALU"],
-                                          floor_ms=ent["valu_issue_ms"],
-                                          frac_of_launch=round(ent["valu_issue_ms"] / kernels[dom]["avg_launch_ms"], 3),
-                                          # the same with the rate MEASURED for plain f32 ops at 4-8 waves per SIMD
-                                          # (tools/microbench/valu_rate.hip, profiles/r01n_valu_rate_microbench.txt:
-                                          # v_fma / v_mul 3.0-3.3 cycles, v_add_f32_dpp 4.4-4.7, v_exp 8.3)
-                                          measured_rate_floor_ms=round(ent["SQ_INSTS_VALU"] * 3.0 / (1024 * 2.4e9) * 1e3, 4),
-                                          frac_of_launch_at_measured_rate=round(
-                                              ent["SQ_INSTS_VALU"] * 3.0 / (1024 * 2.4e9) * 1e3 / kernels[dom]["avg_launch_ms"], 3),
-                                          # launch time in SIMD-cycles (1024 SIMDs x 2.4 GHz) per VALU wave-instruction:
-                                          # 2 = the SIMD-32 issue peak, 4 = what one wave alone sustains
-                                          simd_cycles_per_valu_instruction=round(
-                                              kernels[dom]["avg_launch_ms"] * 1e-3 * 1024 * 2.4e9 / ent["SQ_INSTS_VALU"], 2))
-    except (OSError, ValueError):
-        pass
+    launch_ms = kernels[dom]["avg_launch_ms"]
+    hbm_achieved = alg[dom] / (launch_ms * 1e-3) / 1e9
+    # Committed counter summaries (PMC collection cannot run inside a timed bench): used ONLY when they were taken
+    # on this workload with these flags (their "_meta"), otherwise the fields stay null.
+    this_meta = dict(workload=args.workload, sh_degree=D, loss=args.loss, forward_only=bool(args.forward_only),
+                     reference_rects=bool(args.reference_rects), n_gpus=n_gpus)
+
+    def committed(fname):
+        try:
+            with open(os.path.join(ROOT, "profiles", fname)) as fh:
+                d = json.load(fh)
+        except (OSError, ValueError):
+            return None
+        meta = d.get("_meta") or {}
+        return d if all(meta.get(k) == val for k, val in this_meta.items()) else None
+
+    pmc = committed("pmc_traffic_latest.json")
+    traffic = (pmc or {}).get(dom, {}).get("hbm_bytes_per_launch")
+    sq = committed("sq_counters_latest.json")
+    ent = next((val for k, val in (sq or {}).items() if k.split("<")[0] == dom and isinstance(val, dict)), None)
+    hbm = dict(achieved=round(hbm_achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_achieved / HBM_PEAK_GBS, 4),
+               algorithmic_bytes_per_launch=int(alg[dom]))
+    valu_bound = dom in ("k_blend_backward", "k_blend_forward")  # bound by VALU issue, not bytes
+    if valu_bound and ent and ent.get("SQ_INSTS_VALU"):
+        # VALU issue roofline: wave-instructions per launch (SQ_INSTS_VALU of the committed counter pass on this same
+        # workload) over the LIVE launch time, against one wave64 VALU op per 2 cycles per SIMD-32
+        ginst = ent["SQ_INSTS_VALU"] / (launch_ms * 1e-3) / 1e9
+        roofline = dict(kernel=dom, bound="valu", achieved=round(ginst, 1), peak=VALU_PEAK_GINST,
+                        unit="G wave-instr/s", frac=round(ginst / VALU_PEAK_GINST, 4), traffic=traffic,
+                        avg_launch_ms=round(launch_ms, 4), wave_instructions_per_launch=ent["SQ_INSTS_VALU"],
+                        # the same against the rate MEASURED for plain f32 ops at 4-8 waves per SIMD
+                        # (tools/microbench/valu_rate.hip: v_fma / v_mul 3.0-3.3 cycles, v_add_f32_dpp 4.4-4.7, v_exp 8.3)
+                        frac_of_measured_3cycle_rate=round(ginst / (1024 * 2.4 / 3.0), 4), hbm=hbm)
+    else:
+        roofline = dict(kernel=dom, bound="hbm", achieved=hbm["achieved"], peak=HBM_PEAK_GBS, unit="GB/s",
+                        frac=hbm["frac"], traffic=traffic, avg_launch_ms=round(launch_ms, 4),
+                        algorithmic_bytes_per_launch=int(alg[dom]),
+                        note=("VALU-issue-bound kernel (DESIGN.md section 4); no counter summary committed for this "
+                              "workload, so only its HBM figure is given") if valu_bound else None)
     # whole path: sum over kernels of (algorithmic bytes per launch x launches per step)
     b_path = sum(alg.get(k, 0) * d["launches_per_step"] for k, d in kernels.items())
     raster_ms = sum(k["ms_per_step"] for k in kernels.values())
-
-    # SURVEY.md 8(d)'s whole-path figure, as written there: the bytes the REFERENCE's algorithm moves for this
-    # frame (its instance count, 64-bit keys, ceil((32+bit)/8) sort passes, grad zero-fill) over this path's time
-    n_pass = (32 + tile_bits + 7) // 8
-    Rr = stats["R_reference_binning"]
-    b_ref_fwd = (P * (44 + 12 * M) + P * 8 + P_vis * 67 + P * 8 + P * 20 + Rr * 12 + Rr * 24 * n_pass + Rr * 8
-                 + tiles * 8 + Rr * 44 + W * H * 28)
-    b_ref_bwd = (W * H * 24 + Rr * 40 + Rr * 36 + P * (108 + 12 * M) + P_vis * (111 + 12 * M) + P_vis * (64 + 12 * M))
-    b_ref = b_ref_fwd + (0 if args.forward_only else b_ref_bwd)
 
     ms_per_step = elapsed / args.steps * 1e3
     mpix = n_gpus * W * H * args.steps / elapsed / 1e6
@@ -366,11 +435,7 @@ def main():
         "fps": round(1e3 / ms_per_step * n_gpus, 2),
         "roofline": roofline,
         "whole_path": {"kernel_ms_per_step": round(raster_ms, 4), "algorithmic_GB_per_step": round(b_path / 1e9, 3),
-                       "alg_GBps_over_kernel_time": round(b_path / (raster_ms * 1e-3) / 1e9, 1) if raster_ms else None,
-                       # the reference algorithm's bytes for the same frame (formula of SURVEY.md 8(d)) / step time
-                       "reference_algorithm_GB_per_step": round(b_ref / 1e9, 3), "sort_passes_reference": n_pass,
-                       "reference_algorithm_GBps": round(b_ref / (ms_per_step * 1e-3) / 1e9, 1),
-                       "reference_algorithm_frac_of_peak": round(b_ref / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)},
+                       "alg_GBps_over_kernel_time": round(b_path / (raster_ms * 1e-3) / 1e9, 1) if raster_ms else None},
         "kernels": {k: {kk: (round(vv, 4) if isinstance(vv, float) else vv) for kk, vv in d.items()}
                     for k, d in sorted(kernels.items(), key=lambda kv: -kv[1]["ms_per_step"])},
         "workload_stats": stats,
@@ -380,7 +445,6 @@ def main():
         # pairs per second of each blend kernel's own time (contributors = n_contrib summed over the image)
         "work_units": {
             "Minstances_per_s": round(stats["R"] / (ms_per_step * 1e-3) / 1e6, 1),
-            "Minstances_per_s_reference_binning": round(stats["R_reference_binning"] / (ms_per_step * 1e-3) / 1e6, 1),
             "Gpairs_per_s_blend_forward": (round(stats["mean_contrib_per_pixel"] * W * H /
                                                  (kernels["k_blend_forward"]["avg_launch_ms"] * 1e-3) / 1e9, 2)
                                            if "k_blend_forward" in kernels else None),
@@ -389,6 +453,19 @@ def main():
                                             if "k_blend_backward" in kernels else None),
         },
     }
+    if n_gpus > 1:
+        def mode_line(r):
+            ms = r["elapsed"] / args.steps * 1e3
+            return dict(value=round(n_gpus * W * H * args.steps / r["elapsed"] / 1e6, 2), unit="Mpixels/s",
+                        ms_per_step=round(ms, 4), collective_bytes_per_step=r["collective_bytes_per_step"],
+                        broadcast_of_the_gaussian_buffer_ms=round(r["broadcast_ms"], 3),
+                        gaussian_buffer_bytes=P * MV.floats_per_gaussian(M) * 4)
+        out["sync_modes"] = {args.sync_mode: mode_line(main_run)}
+        if args.sync_mode == "scatter" and not (args.single_sync_mode or args.forward_only or args.no_adam):
+            del main_run, activated
+            torch.cuda.empty_cache()
+            out["sync_modes"]["allreduce"] = mode_line(run_mode("allreduce", survey=False))
+        out["dist_backend"] = args.dist_backend
 
     if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline and not args.forward_only:
         out["cpu_baseline"] = cpu_baseline(g, cam, dcol, dacc, W, H, D)

@@ -93,3 +93,63 @@ def reduce_gradients(grad, dst=0, group=None, all_ranks=False):
         else:
             _collective(t, lambda x: dist.reduce(x, dst=dst, op=dist.ReduceOp.SUM, group=group), group)
     return grad
+
+
+def launch_local_ranks(argv, n_ranks, extra_env=None, timeout=None, out=None, err=None):
+    """One process per GPU on this node WITHOUT an external launcher: starts `n_ranks` children running `argv`
+    (rank r gets RANK = LOCAL_RANK = r, WORLD_SIZE, MASTER_ADDR = 127.0.0.1 and a free MASTER_PORT -- what
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` would set), relays rank 0's
+    stdout to `out` (default: this process's stdout) and every rank's stderr to `err`, and returns the exit status:
+    0 only when every rank exited 0.  When a rank fails the others are terminated (by pid) so a dead peer cannot
+    leave them waiting in a collective.  The caller must not have touched the GPU: the children own the devices.
+    """
+    import os
+    import socket
+    import subprocess
+    import sys
+    import time
+
+    out = sys.stdout if out is None else out
+    err = sys.stderr if err is None else err
+    with socket.socket() as s:  # a free rendezvous port on the loopback interface
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n_ranks):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n_ranks), LOCAL_WORLD_SIZE=str(n_ranks),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: RCCL needs it on this host driver
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
+                                      stderr=None if err is sys.stderr else subprocess.PIPE, text=True))
+    t0 = time.monotonic()
+    status = 0
+    pending = set(range(n_ranks))
+    while pending:
+        for r in sorted(pending):
+            rc = procs[r].poll()
+            if rc is None:
+                continue
+            pending.discard(r)
+            if rc != 0 and status == 0:
+                status = rc if rc > 0 else 1
+                print("[launch_local_ranks] rank %d exited with status %d; stopping the other ranks" % (r, rc), file=err)
+                for q in pending:
+                    procs[q].terminate()
+        if pending and timeout is not None and time.monotonic() - t0 > timeout:
+            status = status or 124
+            print("[launch_local_ranks] timeout after %.0f s; stopping ranks %s" % (timeout, sorted(pending)), file=err)
+            for q in pending:
+                procs[q].kill()
+            timeout = None
+        if pending:
+            time.sleep(0.05)
+    text = procs[0].stdout.read() if procs[0].stdout else ""
+    if text:
+        out.write(text)
+        out.flush()
+    if err is not sys.stderr:
+        for p in procs:
+            if p.stderr:
+                err.write(p.stderr.read())
+    return status

@@ -206,6 +206,48 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
+def test_launch_local_ranks_gloo():
+    """bench.py --gpus N without an external launcher (gs_livm_amd.multiview.launch_local_ranks): N children with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set rendezvous over gloo, rank 0's line is relayed, status 0."""
+    import io
+    import json
+    import sys
+    child = ("import os, json, torch, torch.distributed as dist\n"
+             "dist.init_process_group('gloo', rank=int(os.environ['RANK']), world_size=int(os.environ['WORLD_SIZE']))\n"
+             "assert os.environ['MASTER_ADDR'] == '127.0.0.1' and os.environ['LOCAL_RANK'] == os.environ['RANK']\n"
+             "t = torch.tensor([float(os.environ['RANK']) + 1.0]); dist.all_reduce(t)\n"
+             "if dist.get_rank() == 0: print(json.dumps({'n_gpus': dist.get_world_size(), 'sum': float(t)}))\n"
+             "dist.destroy_process_group()\n")
+    buf = io.StringIO()
+    assert MV.launch_local_ranks([sys.executable, "-c", child], 3, out=buf, timeout=120) == 0
+    line = [ln for ln in buf.getvalue().splitlines() if ln.startswith("{")]
+    assert len(line) == 1 and json.loads(line[0]) == {"n_gpus": 3, "sum": 6.0}
+
+
+def test_launch_local_ranks_reports_a_failed_rank():
+    """a rank that dies takes the job down with a non-zero status instead of leaving its peers waiting."""
+    import io
+    import sys
+    import time
+    bad = "import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(60)\n"
+    t0 = time.time()
+    rc = MV.launch_local_ranks([sys.executable, "-c", bad], 2, out=io.StringIO(), err=io.StringIO(), timeout=120)
+    assert rc == 3 and time.time() - t0 < 30
+
+
+def test_bench_refuses_a_rank_count_it_cannot_run():
+    """python bench.py --gpus 2 on a host with fewer GPUs must fail loudly (never bench one GPU under n_gpus = 2)."""
+    import subprocess
+    import sys
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("needs a host with fewer than 2 GPUs")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], capture_output=True, text=True,
+                       env=env, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and not r.stdout.strip()
+
+
 def test_exchange_steps_world_size_2_gloo():
     ctx = mp.get_context("spawn")
     q = ctx.Queue()

@@ -44,9 +44,24 @@ def split_sorts(name, lst):
     return {name: [x for x in lst if x[1] * 4 > big], name + "[depth]": [x for x in lst if x[1] * 4 <= big]}
 
 
-def main(fetch_dir, write_dir, out_path):
+META_DEFAULT = {"workload": "C3", "sh_degree": 0, "loss": "seeded", "forward_only": False, "reference_rects": False,
+                "n_gpus": 1}
+
+
+def parse_meta(pairs):
+    """key=value arguments describing the profiled bench command; bench.py prints a committed summary's figures only
+    when its _meta equals the run's own workload / flags."""
+    meta = dict(META_DEFAULT)
+    for kv in pairs:
+        k, v = kv.split("=", 1)
+        meta[k] = json.loads(v) if v in ("true", "false") or v.lstrip("-").isdigit() else v
+    return meta
+
+
+def main(fetch_dir, write_dir, out_path, *meta):
     f, w = load(fetch_dir, "FETCH_SIZE"), load(write_dir, "WRITE_SIZE")
-    out = {"_doc": "HBM bytes per launch = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024 (see tools/pmc_summary.py)"}
+    out = {"_doc": "HBM bytes per launch = 2 * FETCH_SIZE KiB * 1024 + WRITE_SIZE KiB * 1024 (see tools/pmc_summary.py)",
+           "_meta": parse_meta(meta)}
     for k in sorted(set(f) | set(w)):
         fs, ws = split_sorts(k, f.get(k, [])), split_sorts(k, w.get(k, []))
         for kk in sorted(set(fs) | set(ws)):
@@ -60,9 +75,9 @@ def main(fetch_dir, write_dir, out_path):
                        "hbm_bytes_per_launch": round(fetch_b + write_b)}
     json.dump(out, open(out_path, "w"), indent=1, sort_keys=True)
     for k, v in out.items():
-        if k != "_doc":
+        if not k.startswith("_"):
             print("%-28s fetch %8.1f MB  write %8.1f MB" % (k, v["fetch_bytes"] / 1e6, v["write_bytes"] / 1e6))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:])

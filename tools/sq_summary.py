@@ -9,7 +9,7 @@ valu_issue_ms = wave-instructions x 2 cycles (wave64 on the SIMD-32 VALU, MI355X
 the time the kernel would need if VALU issue were the only limit."""
 import collections, csv, glob, json, sys
 
-def main(d, out):
+def main(d, out, *meta):
     path = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     disp = collections.defaultdict(set)
@@ -25,7 +25,8 @@ def main(d, out):
         if r["Dispatch_Id"] not in disp[name]:
             disp[name].add(r["Dispatch_Id"])
             dur[name] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
-    res = {"_doc": __doc__.strip().split("\n\n")[-1]}
+    from pmc_summary import parse_meta
+    res = {"_doc": __doc__.strip().split("\n\n")[-1], "_meta": parse_meta(meta)}
     for k in sorted(agg, key=lambda k: -dur[k]):
         n = len(disp[k])
         c = {cn: v / n for cn, v in agg[k].items()}
@@ -42,4 +43,4 @@ def main(d, out):
     json.dump(res, open(out, "w"), indent=1)
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(*sys.argv[1:])
