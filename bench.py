@@ -343,7 +343,8 @@ def main():
         P_vis = int((radii > 0).sum())
         v = G.state_views(fw[5], fw[6], fw[7], P, R, W, H)
         ln = (v["ranges"][:, 1] - v["ranges"][:, 0]).float()
-        R_bwd = int(v["quad_last"].long().max(1).values.sum())
+        walk = v["quad_last"].long().max(1).values  # list entries the backward walks, per tile
+        R_bwd = int(walk.sum())
         # instance count of the REFERENCE's binning (getRect on the 3-sigma radius, auxiliary.h:46-57) for the same
         # frame: the footprint-box culling emits fewer
         vis = radii > 0
@@ -355,6 +356,9 @@ def main():
         stats = dict(P=P, P_vis=P_vis, R=R, R_reference_binning=R_ref, R_walked_by_backward=R_bwd, tiles=int(ln.numel()),
                      mean_tile_list=float(ln.mean()), max_tile_list=int(ln.max()),
                      mean_contrib_per_pixel=float(v["n_contrib"].float().mean()),
+                     backward_walk_per_tile=dict(mean=float(walk.float().mean()), max=int(walk.max()),
+                                                 p50=int(walk.float().quantile(0.5)), p90=int(walk.float().quantile(0.9)),
+                                                 p99=int(walk.float().quantile(0.99))),
                      binning="reference rectangles" if args.reference_rects else "footprint-culled (default)")
         del fw, v
     tiles = stats["tiles"]

@@ -148,6 +148,7 @@ struct ImageState {
   uint32_t* quad_last;  // [tiles][4] max n_contrib over each 8x8 quad's pixels (bounds the backward walk)
   float* final_T;       // [H*W]
   uint32_t* n_contrib;  // [H*W]
+  uint32_t* tile_order; // [tiles] backward only: tile ids by descending length of the list walk (k_tile_order)
   static ImageState carve(char* blob, int W, int H, size_t* bytes = nullptr) {
     Carver c(blob);
     ImageState s;
@@ -157,6 +158,7 @@ struct ImageState {
     s.quad_last = c.take<uint32_t>(tiles * 4);
     s.final_T = c.take<float>(N);
     s.n_contrib = c.take<uint32_t>(N);
+    s.tile_order = c.take<uint32_t>(tiles);
     if (bytes) *bytes = align_up(c.off) + ALIGN;
     return s;
   }

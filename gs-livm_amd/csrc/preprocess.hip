@@ -829,7 +829,7 @@ __device__ __forceinline__ void swap_add16_(float& a, float& b) {
 __global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
     GeomState g, const float4* __restrict__ grad_inst, uint8_t* __restrict__ inst_flag,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-    float* __restrict__ dL_dcolor) {
+    float* __restrict__ dL_dcolor, const float ddelx_dx, const float ddely_dy) {
   const int lane = threadIdx.x & 63;
   const uint32_t nwaves = gridDim.x * (PRE_BLOCK / 64);
   const uint32_t wid = blockIdx.x * (PRE_BLOCK / 64) + (threadIdx.x >> 6);
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
           const float4 c = grad_inst[slot * GRAD_F4 + 2];
           v0 += a.x; v1 += a.y; v2 += a.z; v3 += a.w;
           v4 += b.x; v5 += b.y; v6 += b.z; v7 += b.w;
-          v8 += c.x;
+          v8 += (c.x + c.y) + (c.z + c.w);  // the four 16-lane-row sums of dLG the tile kernel leaves
         }
       }
     }
@@ -871,11 +871,19 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
     v8 = row_allsum_(v8);
     v8 += dpp_get_<0x142, 0xA>(v8);  // row_bcast:15
     v8 += dpp_get_<0x143, 0xC>(v8);  // row_bcast:31 -> total in lane 63
-    // record layout: (col r,g,b, mean2D.x | mean2D.y, conic.x, conic.y, conic.w | opacity)
+    // The records hold RAW pixel sums (colour r g b | S3 = sum dLG dx, S4 = sum dLG dy | S5 = sum dLG dx^2,
+    // S6 = sum dLG dx dy, S7 = sum dLG dy^2 | sum dLG), dLG = G dL/dalpha.  The factors every pixel and every instance
+    // of the Gaussian share are applied here, ONCE per Gaussian (backward.cu:561-562, 583-597):
+    //   dL/dmean2D = -(conic (S3, S4)) * opacity * (W/2, H/2),  dL/dconic = -1/2 opacity (S5, S6, S7),  dL/dopacity = sum dLG
+    const float S3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), 16));
+    const float S4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0), 32));
+    const float4 ra = g.splats[(size_t)id * SPLAT_F4 + 0];  // (x, y, conic.x, conic.y)
+    const float4 rb = g.splats[(size_t)id * SPLAT_F4 + 1];  // (conic.z, opacity, r, g)
+    const float op = rb.y, mc = -0.5f * op;
     if (lane == 0) { dL_dcolor[3 * id] = w0; dL_dcolor[3 * id + 1] = w1; }
-    if (lane == 16) { dL_dcolor[3 * id + 2] = w0; dL_dmean2D[3 * id] = w1; }
-    if (lane == 32) { dL_dmean2D[3 * id + 1] = w0; dL_dconic[4 * id] = w1; }
-    if (lane == 48) { dL_dconic[4 * id + 1] = w0; dL_dconic[4 * id + 3] = w1; }
+    if (lane == 16) { dL_dcolor[3 * id + 2] = w0; dL_dmean2D[3 * id] = -(ra.z * S3 + ra.w * S4) * (op * ddelx_dx); }
+    if (lane == 32) { dL_dmean2D[3 * id + 1] = -(rb.x * S4 + ra.w * S3) * (op * ddely_dy); dL_dconic[4 * id] = w1 * mc; }
+    if (lane == 48) { dL_dconic[4 * id + 1] = w0 * mc; dL_dconic[4 * id + 3] = w1 * mc; }
     if (lane == 63) dL_dopacity[id] = v8;
   }
 }
@@ -1255,7 +1263,7 @@ hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningStat
     const int want = (fp.P + PRE_BLOCK / 64 - 1) / (PRE_BLOCK / 64);
     const int grid = want < 4096 ? want : 4096;
     hipLaunchKernelGGL(k_gather_records, dim3(grid), dim3(PRE_BLOCK), 0, s, g, b.grad_inst, b.inst_flag, dL_dmean2D,
-                       dL_dconic, dL_dopacity, dL_dcolor);
+                       dL_dconic, dL_dopacity, dL_dcolor, 0.5f * (float)fp.W, 0.5f * (float)fp.H);
   }
   return hipGetLastError();
 }

@@ -73,6 +73,14 @@ __device__ __forceinline__ float row_allsum(float v) {
   v += dpp_full<0x128>(v);  // row_ror:8
   return v;
 }
+// three 16-lane-row sums with the steps of the three chains interleaved: a DPP instruction that reads the VGPR the
+// previous VALU instruction wrote needs two wait states, which the neighbouring chains fill
+__device__ __forceinline__ void row_allsum3(float& a, float& b, float& c) {
+  a += dpp_full<0xB1>(a); b += dpp_full<0xB1>(b); c += dpp_full<0xB1>(c);     // quad_perm [1,0,3,2]
+  a += dpp_full<0x4E>(a); b += dpp_full<0x4E>(b); c += dpp_full<0x4E>(c);     // quad_perm [2,3,0,1]
+  a += dpp_full<0x124>(a); b += dpp_full<0x124>(b); c += dpp_full<0x124>(c);  // row_ror:4
+  a += dpp_full<0x128>(a); b += dpp_full<0x128>(b); c += dpp_full<0x128>(c);  // row_ror:8
+}
 __device__ __forceinline__ void wave_sum8(float v0, float v1, float v2, float v3, float v4, float v5, float v6,
                                           float v7, float& w0, float& w1) {
   swap_add32(v0, v4);  // v0: lo = v0 partials, hi = v4 partials
@@ -100,6 +108,21 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
   return ((uint64_t)hi << 32) | lo;
 }
 
+// log2(e) x the reference's power = -1/2 (A dx^2 + C dy^2) - B dx dy of a pixel at offset (dx, dy) from the splat
+// centre (forward.cu:362-366), from the pre-scaled conic terms A' = -1/2 log2(e) A, B' = -log2(e) B,
+// C' = -1/2 log2(e) C.  ONE fixed sequence of roundings -- A' dx^2 + dy (C' dy + B' dx), explicit fmas -- shared by the
+// forward and the backward blend so that both take bit-identical alpha / skip decisions for every (pixel, splat)
+// pair; the backward evaluates it for four pixels of one column per lane and shares dx, dx^2 and A' dx^2 among them.
+__device__ __forceinline__ float splat_power_shared(float Adx2, float Bp, float Cp, float dx, float dy) {
+  const float Cdy = Cp * dy;
+  const float t = __builtin_fmaf(Bp, dx, Cdy);
+  return __builtin_fmaf(t, dy, Adx2);
+}
+__device__ __forceinline__ float splat_power(float Ap, float Bp, float Cp, float dx, float dy) {
+  const float dx2 = dx * dx;
+  return splat_power_shared(Ap * dx2, Bp, Cp, dx, dy);
+}
+
 // Exact-conservative ellipse-vs-quad test.  f(u, v) = 1/2 (A u^2 + C v^2) + B u v = -power of a pixel at offset (u, v)
 // from the splat centre; the pixel centres of a quad fill [x0, x0 + 7] x [y0, y0 + 7].  f is convex (the caller
 // only asks for positive-definite conics), so its minimum over the rectangle is 0 if the centre lies inside and
@@ -107,9 +130,10 @@ __device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
 // of the quad can reach alpha >= 1/255 (tau carries the slack, footprint_tau): the quad skips the splat exactly as
 // the reference skips it pixel by pixel (forward.cu:374-376, backward.cu:476-478).  The footprint BOX alone lets
 // ~25 % of the (quad, splat) pairs through that this test rejects (corners of slanted ellipses).
+template <int EXTENT = 7>  // the rectangle of pixel centres is [x0, x0 + EXTENT] x [y0, y0 + EXTENT]: 7 = quad, 15 = tile
 __device__ __forceinline__ bool ellipse_reaches_quad(float cx, float cy, float A, float B, float C, float tau,
                                                      float x0, float y0) {
-  const float u0 = x0 - cx, u1 = u0 + 7.0f, v0 = y0 - cy, v1 = v0 + 7.0f;
+  const float u0 = x0 - cx, u1 = u0 + (float)EXTENT, v0 = y0 - cy, v1 = v0 + (float)EXTENT;
   if (u0 <= 0.0f && u1 >= 0.0f && v0 <= 0.0f && v1 >= 0.0f) return true;
   const float nBiC = -B * __builtin_amdgcn_rcpf(C), nBiA = -B * __builtin_amdgcn_rcpf(A);
   float fmin = 3.0e38f;
@@ -217,7 +241,7 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
     // current hit is blended (two register sets, no copies), so their latency hides behind ~30 VALU ops.
     auto blend = [&](const float4 ra, const float4 rb, const float4 rc, const int jj) {
       const float dx = ra.x - pfx, dy = ra.y - pfy;
-      const float power = ra.z * (dx * dx) + rb.x * (dy * dy) + ra.w * (dx * dy);  // = log2(e) x the reference's power
+      const float power = splat_power(ra.z, ra.w, rb.x, dx, dy);  // = log2(e) x the reference's power
       const float alpha = fminf(0.99f, rb.y * __builtin_amdgcn_exp2f(power));
       bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
       const float test_T = T * (1.0f - alpha);
@@ -322,7 +346,6 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   const float dacc = inside ? dL_dacc[pid] : 0.f;  // the reference reads this unguarded (backward.cu:497)
   const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
   const float neg_Tf_bg = -T_final * bg_dot;  // per-pixel constant of the background term (backward.cu:578-581)
-  const float ddelx_dx = 0.5f * (float)fp.W, ddely_dy = 0.5f * (float)fp.H;
   float T = T_final;
   float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;  // accum_rec
   float nacc = 1.0f;                      // 1 - accum_acc_rec: the form dL_dalpha uses; its update is one multiply
@@ -383,7 +406,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         const float4 b = sE[jj][1];
         const float blue = sE[jj][2].x;
         const float dx = a.x - pfx, dy = a.y - pfy;
-        const float power = a.z * (dx * dx) + b.x * (dy * dy) + a.w * (dx * dy);  // = log2(e) x the reference's power
+        const float power = splat_power(a.z, a.w, b.x, dx, dy);  // = log2(e) x the reference's power
         const float Graw = __builtin_amdgcn_exp2f(power);
         const float araw = fminf(0.99f, b.y * Graw);
         const bool ok = (pos < lastc) && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
@@ -460,19 +483,224 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       }
       if (any) {
         const size_t slot = sSlot[tid];
-        const float4 cc = sE[tid][2];  // (blue, conic.x, conic.y, conic.z): the plain conic
-        const float op = sE[tid][1].y;  // dL/dG = opacity * dL/dalpha; conic terms carry -0.5 (backward.cu:583-597)
-        const float mx = op * ddelx_dx, my = op * ddely_dy, mc = -0.5f * op;
-        const float gx = -(cc.y * s[3] + cc.z * s[4]);  // dG_ddelx, dG_ddely summed over the pixels (backward.cu:561-562)
-        const float gy = -(cc.w * s[4] + cc.z * s[3]);
-        grad_inst[slot * GRAD_F4 + 0] = make_float4(s[0], s[1], s[2], gx * mx);
-        grad_inst[slot * GRAD_F4 + 1] = make_float4(gy * my, s[5] * mc, s[6] * mc, s[7] * mc);
+        // raw pixel sums; the splat-constant factors (conic, opacity, 1/2 W, 1/2 H) are applied once per GAUSSIAN by
+        // k_gather_records, after its instances have been summed
+        grad_inst[slot * GRAD_F4 + 0] = make_float4(s[0], s[1], s[2], s[3]);
+        grad_inst[slot * GRAD_F4 + 1] = make_float4(s[4], s[5], s[6], s[7]);
         grad_inst[slot * GRAD_F4 + 2] = make_float4(s[8], 0.f, 0.f, 0.f);
         inst_flag[slot] = 1;
         touched[sId[tid]] = 1;  // same value from every writer: a benign race
       }
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// B1 backward blend, ONE WAVE PER 16x16 TILE, four pixels per lane, no barriers.
+//
+// Why: at the 2 M-Gaussian / 1080p shape 84 % of the list entries the backward walks cover all four 8x8 quads of
+// their tile and 93 % of the lanes of a (quad, splat) visit contribute (tools/analyze_blend_visits.py), and half of a
+// one-pixel-per-lane visit is the nine-value cross-lane reduction.  Here lane l owns the pixels (x = l & 15,
+// y = 4 k + (l >> 4)), k = 0..3, of its tile: the nine partial sums are accumulated over the lane's own four pixels in
+// registers first (as fused multiply-adds: no extra instructions) and ONE reduction serves 256 pixels -- 2.9 instead
+// of 7.5 reduction instructions per (quad, splat) -- and the four pixels of a lane share a column, hence dx, dx^2 and
+// A' dx^2 of the power.  The wave owns the whole tile, so the per-instance record is final after the reduction:
+// no per-quad partials in LDS, no combine step, no workgroup barrier; four lanes store the nine RAW pixel sums
+// (the splat-constant factors are applied once per Gaussian by k_gather_records).
+// The list is streamed in sub-chunks of 64 like the forward: each lane gathers one entry (record, slot), tests the
+// splat's exact alpha >= 1/255 ellipse against the TILE, the wave ballots, publishes the entries to a wave-private
+// LDS image and walks the set bits back to front; the next sub-chunk's gather is in flight meanwhile.
+// Replaces renderCUDA backward (reference backward.cu:438-603); sums in a fixed order => bitwise reproducible.
+// ------------------------------------------------------------------------------------------------
+// Order in which the backward takes the tiles: longest list walk first.  A tile is one wave's serial job and the chip
+// holds only about half of a 1080p frame's tiles at once, so in image order the launch ends with a tail of whatever
+// long tiles happened to start late; started in descending order of work, the last tiles to start are the shortest
+// ones (longest-processing-time-first list scheduling).  Counting sort by walk length, one workgroup; the order among
+// tiles of equal length is arbitrary and nothing depends on it (every tile is an independent unit of work).
+__global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict__ quad_last, const int T,
+                                                     uint32_t* __restrict__ order) {
+  __shared__ uint32_t bins[1024];  // bin b = walk length min(w, 1023); scanned from the longest down
+  __shared__ uint32_t wtot[16];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  bins[tid] = 0u;
+  __syncthreads();
+  auto walk = [&](int t) {
+    const uint4 q = *reinterpret_cast<const uint4*>(quad_last + 4 * (size_t)t);
+    const uint32_t m = max(max(q.x, q.y), max(q.z, q.w));
+    return m < 1023u ? m : 1023u;
+  };
+  for (int t = tid; t < T; t += 1024) atomicAdd(&bins[walk(t)], 1u);
+  __syncthreads();
+  const uint32_t v = bins[1023 - tid];  // thread i owns bin 1023 - i: an exclusive scan over i = over longer walks
+  uint32_t inc = v;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint32_t u = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += u;
+  }
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();
+  uint32_t base = inc - v;
+  for (int k = 0; k < w; k++) base += wtot[k];
+  bins[1023 - tid] = base;
+  __syncthreads();
+  for (int t = tid; t < T; t += 1024) order[atomicAdd(&bins[walk(t)], 1u)] = (uint32_t)t;
+}
+
+template <int TW>  // tiles (= waves) per workgroup; the waves never synchronise
+__global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
+    const FrameParams fp, const uint2* __restrict__ ranges, const uint32_t* __restrict__ quad_last_in,
+    const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const uint2* __restrict__ slotinfo,
+    const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
+    const float* __restrict__ dL_dpix, const float* __restrict__ dL_dacc, float* __restrict__ grad_inst,
+    uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_order) {
+  __shared__ float4 sE[TW][64][3];  // (x, y, A', B' | C', opacity, r, g | b, -, -, -) per staged entry
+  __shared__ uint32_t sSlot[TW][64], sId[TW][64];
+  const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  if (blockIdx.x * TW + wq >= fp.gx * fp.gy) return;
+  const int tile = tile_order ? (int)tile_order[blockIdx.x * TW + wq] : blockIdx.x * TW + wq;
+  const uint32_t ql0 = quad_last_in[4 * tile], ql1 = quad_last_in[4 * tile + 1], ql2 = quad_last_in[4 * tile + 2],
+                 ql3 = quad_last_in[4 * tile + 3];
+  const int n = (int)max(max(ql0, ql1), max(ql2, ql3));  // entries [0, n) of the tile's list can carry gradient
+  if (n == 0) return;
+  const int tile_x = tile % fp.gx, tile_y = tile / fp.gx;
+  const uint32_t rbase = ranges[tile].x;
+  const int px = tile_x * TILE + (lane & 15);
+  const float pfx = (float)px;
+  const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
+  const size_t N = (size_t)fp.W * fp.H;
+  const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
+
+  // per-pixel state, k = 0..3 (fully unrolled: registers)
+  float pfy[4], T[4], ar0[4], ar1[4], ar2[4], nacc[4], dp0[4], dp1[4], dp2[4], dacc[4], nTfbg[4];
+  int lastc[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) {
+    const int py = tile_y * TILE + 4 * k + (lane >> 4);
+    const bool inside = px < fp.W && py < fp.H;
+    const size_t pid = (size_t)fp.W * py + px;
+    pfy[k] = (float)py;
+    T[k] = inside ? final_T[pid] : 0.0f;
+    lastc[k] = inside ? (int)n_contrib[pid] : 0;  // a pixel outside the image never takes a splat
+    dp0[k] = inside ? dL_dpix[pid] : 0.f;
+    dp1[k] = inside ? dL_dpix[N + pid] : 0.f;
+    dp2[k] = inside ? dL_dpix[2 * N + pid] : 0.f;
+    dacc[k] = inside ? dL_dacc[pid] : 0.f;  // the reference reads this unguarded (backward.cu:497)
+    nTfbg[k] = -T[k] * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);  // background term (backward.cu:578-581)
+    ar0[k] = ar1[k] = ar2[k] = 0.f;  // accum_rec
+    nacc[k] = 1.0f;                  // 1 - accum_acc_rec
+  }
+
+  // staging of list entry `k` counted from the back of [0, n): record, gradient slot, tile-level hit test
+  float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
+  uint32_t eid = 0, eslot = 0;
+  bool hit = false;
+  auto gather = [&](const int k) {
+    hit = false;
+    if (k < n) {
+      const uint32_t id = point_list[rbase + (uint32_t)(n - 1 - k)];
+      a = splats[(size_t)id * SPLAT_F4 + 0];
+      b = splats[(size_t)id * SPLAT_F4 + 1];
+      c = splats[(size_t)id * SPLAT_F4 + 2];
+      const uint2 si = slotinfo[id];
+      const int x0 = (int)(si.y & 1023u), y0 = (int)((si.y >> 10) & 1023u), rw = (int)(si.y >> 20);
+      eid = id;
+      eslot = si.x + (uint32_t)((tile_y - y0) * rw + (tile_x - x0));
+      // footprint box against the tile, then the ellipse itself (hx < 0: never; hx >= 1e6: indefinite conic, no culling)
+      hit = (a.x + c.z >= tx0) && (a.x - c.z <= tx0 + 15.0f) && (a.y + c.w >= ty0) && (a.y - c.w <= ty0 + 15.0f);
+      if (hit && c.z < 1.0e6f)
+        hit = ellipse_reaches_quad<15>(a.x, a.y, a.z, a.w, b.x, footprint_tau(b.y), tx0, ty0);
+    }
+  };
+  gather(lane);
+  float* const rec_lane = grad_inst + 2 * (lane >> 4);  // lanes 0, 16, 32, 48 store floats (2r, 2r + 1) of a record
+  for (int base = 0; base < n; base += 64) {
+    constexpr float L2E = 1.4426950408889634f;
+    sE[wq][lane][0] = make_float4(a.x, a.y, a.z * (-0.5f * L2E), a.w * (-L2E));
+    sE[wq][lane][1] = make_float4(b.x * (-0.5f * L2E), b.y, b.z, b.w);
+    sE[wq][lane][2] = make_float4(c.x, 0.f, 0.f, 0.f);
+    sSlot[wq][lane] = eslot;
+    sId[wq][lane] = eid;
+    uint64_t m = __ballot(hit);
+    gather(base + 64 + lane);  // the next sub-chunk's gather completes while this one is walked
+    while (m) {
+      const int jj = __builtin_ctzll(m);
+      m &= m - 1;
+      const int pos = n - 1 - (base + jj);  // 0-based index in the tile list == `contributor` after decrement
+      const float4 ea = sE[wq][jj][0];
+      const float4 eb = sE[wq][jj][1];
+      const float blue = sE[wq][jj][2].x;
+      const float dx = ea.x - pfx;
+      const float dx2 = dx * dx;
+      const float Adx2 = ea.z * dx2;
+      // lane-local sums over the lane's four pixels: colour (3), dLG, dLG dy, dLG dy^2 (accumulated as fused
+      // multiply-adds: combining the four pixels costs no instruction of its own)
+      float c0 = 0.f, c1 = 0.f, c2 = 0.f, sG = 0.f, sGy = 0.f, sGyy = 0.f;
+      uint32_t abits = 0u;  // OR of the lane's four alphas: non-zero iff one of its pixels takes the splat
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const float dy = ea.y - pfy[k];
+        const float power = splat_power_shared(Adx2, ea.w, eb.x, dx, dy);  // = log2(e) x the reference's power
+        const float Graw = __builtin_amdgcn_exp2f(power);
+        const float araw = fminf(0.99f, eb.y * Graw);
+        const bool ok = (pos < lastc[k]) && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
+        // Branch-free per lane: a pixel that does not take this splat runs with alpha = 0 and G = 0 -- exact zero
+        // partials, recurrence state untouched bit for bit (see k_blend_backward)
+        const float alpha = ok ? araw : 0.0f;
+        const float oma = 1.0f - alpha;
+        const float rom = __builtin_amdgcn_rcpf(oma);
+        const float Tn = T[k] * rom;  // T / (1 - alpha)
+        const float d0 = eb.z - ar0[k], d1 = eb.w - ar1[k], d2 = blue - ar2[k];
+        if (__ballot(ok) != 0ull) {  // some pixel of this 16 x 4 strip takes the splat
+          const float G = ok ? Graw : 0.0f;
+          const float dch = alpha * Tn;
+          float dL_dalpha = d0 * dp0[k] + d1 * dp1[k] + d2 * dp2[k] + nacc[k] * dacc[k];
+          dL_dalpha *= Tn;
+          dL_dalpha += rom * nTfbg[k];
+          const float dLG = G * dL_dalpha;  // dL/dG up to the opacity factor; also the opacity partial itself
+          const float sy = dLG * dy;
+          c0 = __builtin_fmaf(dch, dp0[k], c0);
+          c1 = __builtin_fmaf(dch, dp1[k], c1);
+          c2 = __builtin_fmaf(dch, dp2[k], c2);
+          sG += dLG;
+          sGy += sy;
+          sGyy = __builtin_fmaf(sy, dy, sGyy);
+        }
+        abits |= __float_as_uint(alpha);
+        // Fold this splat into the "everything behind the next one" accumulators (the reference does it at the top of
+        // its next iteration from saved (last_alpha, last_color), backward.cu:533-543): accum + alpha (c - accum)
+        T[k] = Tn;
+        ar0[k] = __builtin_fmaf(alpha, d0, ar0[k]);
+        ar1[k] = __builtin_fmaf(alpha, d1, ar1[k]);
+        ar2[k] = __builtin_fmaf(alpha, d2, ar2[k]);
+        nacc[k] = nacc[k] * oma;  // 1 - (acc + alpha (1 - acc)) = (1 - acc)(1 - alpha)
+      }
+      if (__ballot(abits != 0u) != 0ull) {
+        // the lane's pixels share dx: sum dLG dx = dx sum dLG, sum dLG dx^2 = dx^2 sum dLG, sum dLG dx dy = dx sum dLG dy
+        float v0 = c0, v1 = c1, v2 = c2, v3 = dx * sG, v4 = sGy, v5 = dx2 * sG, v6 = dx * sGy, v7 = sGyy, g8 = sG;
+        swap_add32(v0, v4);
+        swap_add32(v1, v5);
+        swap_add32(v2, v6);
+        swap_add32(v3, v7);
+        swap_add16(v0, v2);  // rows hold the half-wave-pair sums of v0, v2, v4, v6
+        swap_add16(v1, v3);  // ... of v1, v3, v5, v7
+        row_allsum3(v0, v1, g8);
+        asm volatile("" : "+v"(v0), "+v"(v1), "+v"(g8));
+        const size_t slot = sSlot[wq][jj];
+        // record = the RAW pixel sums: floats 0..7 = colour r g b | dLG dx, dLG dy | dLG dx^2, dLG dx dy, dLG dy^2 (row r
+        // of the wave holds the wave totals of values 2r, 2r + 1), floats 8..11 = the four 16-lane-row sums of dLG
+        // (k_gather_records adds them: two cross-row steps fewer here, once per instance)
+        if ((lane & 15) == 0) {
+          *reinterpret_cast<float2*>(rec_lane + slot * (GRAD_F4 * 4)) = make_float2(v0, v1);
+          grad_inst[slot * (GRAD_F4 * 4) + 8 + (lane >> 4)] = g8;
+        }
+        if (lane == 63) {
+          inst_flag[slot] = 1;
+          touched[sId[wq][jj]] = 1;  // same value from every writer: a benign race
+        }
+      }
+    }
   }
 }
 
@@ -490,10 +718,28 @@ hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                  const float* dL_dpix, const float* dL_dacc, hipStream_t s) {
   ProfScope ps_k_blend_bwd(K_BLEND_BWD, s);
-  // chunks of 128 list entries (64 and 128 measured equal, 256 slower: LDS footprint)
-  hipLaunchKernelGGL(k_blend_backward<128>, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, im.quad_last, b.point_list,
-                     g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst, b.inst_flag,
-                     g.touched);
+  // GSR_BLEND_BACKWARD_QUADS=1 (diagnostics / A-B): the wave-per-quad kernel with its LDS combine step
+  static const bool per_quad = getenv("GSR_BLEND_BACKWARD_QUADS") != nullptr;
+  if (per_quad) {
+    // chunks of 128 list entries (64 and 128 measured equal, 256 slower: LDS footprint)
+    hipLaunchKernelGGL(k_blend_backward<128>, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, im.quad_last,
+                       b.point_list, g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst,
+                       b.inst_flag, g.touched);
+  } else {
+    const int tiles = fp.gx * fp.gy;
+    static const int tw = getenv("GSR_BWD_TW") ? atoi(getenv("GSR_BWD_TW")) : 4;  // experiment knob
+    static const bool image_order = getenv("GSR_BWD_IMAGE_ORDER") != nullptr;     // experiment knob
+    const uint32_t* order = image_order ? nullptr : im.tile_order;
+    if (order) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.quad_last, tiles, im.tile_order);
+#define GSR_LAUNCH_BWD_TILE(TW)                                                                                        \
+  hipLaunchKernelGGL(k_blend_backward_tile<TW>, dim3((tiles + TW - 1) / TW), dim3(64 * TW), 0, s, fp, im.ranges,        \
+                     im.quad_last, b.point_list, g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc,  \
+                     reinterpret_cast<float*>(b.grad_inst), b.inst_flag, g.touched, order)
+    if (tw == 1) GSR_LAUNCH_BWD_TILE(1);
+    else if (tw == 2) GSR_LAUNCH_BWD_TILE(2);
+    else GSR_LAUNCH_BWD_TILE(4);
+#undef GSR_LAUNCH_BWD_TILE
+  }
   return hipGetLastError();
 }
 
