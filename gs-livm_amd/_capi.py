@@ -18,7 +18,8 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 
 class GeometryView(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
-                ("depths", "radii", "splats", "cov3D", "tiles_touched", "point_offsets", "clamped", "depth_order")]
+                ("depths", "radii", "splats", "cov3D", "tiles_touched", "point_offsets", "clamped", "depth_order",
+                 "num_rendered")]
 
 
 class BinningView(C.Structure):
@@ -29,6 +30,27 @@ class ImageView(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in ("ranges", "final_T", "n_contrib", "quad_last")]
 
 
+class MailboxEvent(C.Structure):
+    _fields_ = [("count", C.c_uint), ("ticket_expected", C.c_uint32), ("ticket_seen_before_query", C.c_uint32),
+                ("elapsed_us", C.c_double), ("ticket_seen_after_query", C.c_uint32), ("first_query_result", C.c_int),
+                ("visible_at_query", C.c_int)]
+
+
+class NumRendered(int):
+    """num_rendered as the reference returns it (RasterizeGaussiansCUDA's first element) -- the exact instance count --
+    carrying `key`: what gsr_forward returned, the capacity the binning blob was carved for (== the count after a
+    synchronous forward, >= it after a speculative one).  rasterize_backward / state_views take the key from it."""
+
+    def __new__(cls, exact, key):
+        obj = super().__new__(cls, exact)
+        obj.key = int(key)
+        return obj
+
+
+def _key(R):
+    return int(getattr(R, "key", R))
+
+
 _lib = None
 
 EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_bytes", "gsr_image_bytes",
@@ -36,7 +58,9 @@ EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_byte
            "gsr_higher_msb", "gsr_last_error", "gsr_abi_version", "gsr_kernel_count", "gsr_kernel_name",
            "gsr_profile_enable", "gsr_profile_enable_only", "gsr_profile_read", "gsr_mailbox_slow_path_hits", "gsr_activate", "gsr_activate_backward", "gsr_adam_step",
            "gsr_photometric_loss", "gsr_photometric_loss_workspace", "gsr_init_gaussians", "gsr_ply_row_floats",
-           "gsr_pack_ply_rows", "gsr_model_step", "gsr_set_reference_rects", "gsr_reference_rects")
+           "gsr_pack_ply_rows", "gsr_model_step", "gsr_set_reference_rects", "gsr_reference_rects",
+           "gsr_last_num_rendered", "gsr_set_binning_capacity_hint", "gsr_speculative_forwards",
+           "gsr_speculation_overflows", "gsr_mailbox_slow_path_last")
 
 
 def lib():
@@ -79,6 +103,15 @@ def lib():
     L.gsr_set_reference_rects.argtypes = [ci]
     L.gsr_reference_rects.restype = ci
     L.gsr_reference_rects.argtypes = []
+    L.gsr_last_num_rendered.restype = ci
+    L.gsr_last_num_rendered.argtypes = []
+    L.gsr_set_binning_capacity_hint.restype = C.c_longlong
+    L.gsr_set_binning_capacity_hint.argtypes = [C.c_longlong]
+    for n in ("gsr_speculative_forwards", "gsr_speculation_overflows"):
+        getattr(L, n).restype = C.c_ulonglong
+        getattr(L, n).argtypes = []
+    L.gsr_mailbox_slow_path_last.restype = ci
+    L.gsr_mailbox_slow_path_last.argtypes = [C.POINTER(MailboxEvent)]
     L.gsr_mailbox_slow_path_hits.restype = C.c_ulonglong
     L.gsr_mailbox_slow_path_hits.argtypes = []
     L.gsr_profile_read.restype = ci
@@ -169,6 +202,7 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
                              _ptr(projmatrix), _ptr(campos), float(tan_fovx), float(tan_fovy), int(bool(prefiltered)),
                              _ptr(out_color), _ptr(out_depth), _ptr(out_acc), _ptr(radii) if radii_out else None,
                              int(bool(debug)), _stream()))
+    R = NumRendered(L.gsr_last_num_rendered() if P else 0, R)
     return R, out_color, out_depth, out_acc, radii, gb.tensor, bb.tensor, ib.tensor
 
 
@@ -198,7 +232,7 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
     if P != 0:
         dpix = dL_dout_color.contiguous()
         dacc = dL_dout_acc.contiguous()
-        _check(lib().gsr_backward(P, int(degree), M, int(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh),
+        _check(lib().gsr_backward(P, int(degree), M, _key(R), _ptr(background), W, H, _ptr(means3D), _ptr(sh),
                                   _ptr(colors), _ptr(scales), float(scale_modifier), _ptr(rotations),
                                   _ptr(cov3D_precomp), _ptr(viewmatrix), _ptr(projmatrix), _ptr(campos),
                                   float(tan_fovx), float(tan_fovy), _ptr(radii), _ptr(geomBuffer),
@@ -208,6 +242,30 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
                                   int(bool(debug)), _stream()))
     out = (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
     return out + (dL_dconic,) if return_conic else out
+
+
+def last_num_rendered():
+    """Exact instance count of the calling thread's last forward (no device access)."""
+    return int(lib().gsr_last_num_rendered())
+
+
+def set_binning_capacity_hint(capacity):
+    """Test / tuning hook (include/gsraster.h): the calling thread's NEXT forward allocates its binning blob for
+    `capacity` instances (smaller than the frame's count forces the overflow path); 0 = forget the history (next
+    forward synchronous); None = no override."""
+    return int(lib().gsr_set_binning_capacity_hint(-1 if capacity is None else int(capacity)))
+
+
+def speculation_stats():
+    L = lib()
+    return dict(speculative_forwards=int(L.gsr_speculative_forwards()), overflows=int(L.gsr_speculation_overflows()),
+                mailbox_slow_path_hits=int(L.gsr_mailbox_slow_path_hits()))
+
+
+def mailbox_slow_path_last():
+    ev = MailboxEvent()
+    _check(lib().gsr_mailbox_slow_path_last(C.byref(ev)))
+    return {n: getattr(ev, n) for n, _ in MailboxEvent._fields_}
 
 
 def set_reference_rects(on):
@@ -260,8 +318,11 @@ def state_views(geomBuffer, binningBuffer, imageBuffer, P, R, W, H):
                    final_T=_sub(imageBuffer, iv.final_T, W * H, torch.float32).view(H, W),
                    n_contrib=_sub(imageBuffer, iv.n_contrib, W * H, torch.int32).view(H, W),
                    quad_last=_sub(imageBuffer, iv.quad_last, T * 4, torch.int32).view(T, 4))
+        exact = int(_sub(geomBuffer, gv.num_rendered, 1, torch.int32)[0])  # the forward's count, from device memory
+        out["num_rendered"] = exact
+        key, R = _key(R), exact
         if R:
-            _check(L.gsr_binning_view_of(_ptr(binningBuffer), R, C.byref(bv)))
+            _check(L.gsr_binning_view_of(_ptr(binningBuffer), key, C.byref(bv)))
             # tile of instance i = the tile whose range contains i (the last sort pass marks ranges instead of
             # storing the sorted tile ids)
             rg = out["ranges"].long()

@@ -3,7 +3,9 @@
 // (reference rasterizer_impl.cu:181-342, :346-457); all device work is in the sibling .hip files.
 #include "../../include/gsraster.h"
 
+#include <algorithm>
 #include <atomic>
+#include <mutex>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -41,22 +43,33 @@ static int fail(int code, const char* fmt, ...) {
 
 // ---- optional event profiler -------------------------------------------------------------------
 namespace gsr {
-bool g_prof_on = false;
-unsigned long long g_prof_mask = ~0ull;
+std::atomic<bool> g_prof_on{false};
+std::atomic<unsigned long long> g_prof_mask{~0ull};
+static std::mutex g_ev_mu;            // guards the pool: the reference calls the rasterizer from several threads
 static std::vector<hipEvent_t> g_ev;  // pool: [2*i] start, [2*i+1] stop
 static std::vector<int> g_ev_id;
 static size_t g_ev_used = 0;
 void prof_begin(int id, hipStream_t s) {
+  g_ev_mu.lock();  // released by prof_end: a start / stop pair is recorded as a unit
   if (g_ev_used == g_ev_id.size()) {
     hipEvent_t a, b;
-    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { g_prof_on = false; return; }
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
+      g_prof_on = false;
+      g_ev_id.push_back(-1);  // keeps prof_end's bookkeeping consistent; never read (id -1)
+      g_ev.push_back(nullptr); g_ev.push_back(nullptr);
+      return;
+    }
     g_ev.push_back(a); g_ev.push_back(b); g_ev_id.push_back(id);
   }
   g_ev_id[g_ev_used] = id;
-  (void)hipEventRecord(g_ev[2 * g_ev_used], s);
+  if (g_ev[2 * g_ev_used]) (void)hipEventRecord(g_ev[2 * g_ev_used], s);
 }
 void prof_end(hipStream_t s) {
-  if (g_ev_used < g_ev_id.size()) { (void)hipEventRecord(g_ev[2 * g_ev_used + 1], s); g_ev_used++; }
+  if (g_ev_used < g_ev_id.size() && g_ev[2 * g_ev_used + 1]) {
+    (void)hipEventRecord(g_ev[2 * g_ev_used + 1], s);
+    g_ev_used++;
+  }
+  g_ev_mu.unlock();
 }
 }  // namespace gsr
 static const char* const kKernelNames[K_COUNT] = {
@@ -71,6 +84,7 @@ extern "C" {
 int gsr_kernel_count(void) { return K_COUNT; }
 const char* gsr_kernel_name(int id) { return (id >= 0 && id < K_COUNT) ? kKernelNames[id] : ""; }
 int gsr_profile_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_ev_mu);
   if (on) g_ev_used = 0;  // a fresh recording; disabling keeps what was recorded for gsr_profile_read
   g_prof_on = on != 0;
   g_prof_mask = ~0ull;
@@ -83,6 +97,7 @@ int gsr_profile_enable_only(const int* kernel_ids, int n) {
     if (kernel_ids[i] < 0 || kernel_ids[i] >= K_COUNT) return fail(GSR_ERR_INVALID_ARGUMENT, "bad kernel id");
     m |= 1ull << kernel_ids[i];
   }
+  std::lock_guard<std::mutex> lk(g_ev_mu);
   g_ev_used = 0;
   g_prof_mask = m;
   g_prof_on = true;
@@ -90,13 +105,14 @@ int gsr_profile_enable_only(const int* kernel_ids, int n) {
 }
 int gsr_profile_read(int max_ids, double* total_ms, int* launches) {
   const int n = max_ids < K_COUNT ? max_ids : (int)K_COUNT;
+  std::lock_guard<std::mutex> lk(g_ev_mu);
   for (int i = 0; i < n; i++) { total_ms[i] = 0.0; launches[i] = 0; }
   for (size_t i = 0; i < g_ev_used; i++) {
     HIP_TRY(hipEventSynchronize(g_ev[2 * i + 1]));
     float ms = 0.f;
     HIP_TRY(hipEventElapsedTime(&ms, g_ev[2 * i], g_ev[2 * i + 1]));
     const int id = g_ev_id[i];
-    if (id < n) { total_ms[id] += ms; launches[id]++; }
+    if (id >= 0 && id < n) { total_ms[id] += ms; launches[id]++; }
   }
   g_ev_used = 0;
   return n;
@@ -155,7 +171,156 @@ static FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx
   return fp;
 }
 
-static unsigned long long g_mailbox_slow_hits = 0;  // forwards whose instance count arrived through the stream query
+// ---- shared host state ---------------------------------------------------------------------------------------
+static std::atomic<unsigned long long> g_mailbox_slow_hits{0};  // forwards whose count arrived through the stream query
+static std::atomic<unsigned long long> g_speculative_forwards{0}, g_speculation_overflows{0};
+
+// What the slow path saw the last time it fired (gsr_mailbox_slow_path_last): enough to tell a late-visible store
+// (the word appears some time after the stream has drained) from a late dispatch (the word is there as soon as a HIP
+// call has been made) the next time it occurs naturally.
+static std::mutex g_slow_mu;
+static gsr_mailbox_event g_slow_last = {0, 0, 0, 0.0, 0, 0, 0};
+
+// Per host thread and device: the mailbox, the kernel's "workgroups done" word, the two digit-histogram buffers and the
+// capacity prediction.  A host thread is inside gsr_forward for one forward at a time, and its forwards must be
+// ordered on the device (ONE stream per host thread at a time, as the reference's default-stream use): the done
+// word and the histogram pair are re-used by consecutive calls.  A thread that switches streams is detected and made
+// safe (the library drains the previous stream before re-using the words) instead of corrupting the counter.
+struct ThreadCtx {
+  unsigned long long* mailbox = nullptr;      // host pointer (page-locked, device-mapped)
+  unsigned long long* mailbox_dev = nullptr;
+  unsigned long long* done_counter = nullptr; // device: (workgroups done << 40 | sum) + 2 x [4][256] digit histograms
+  int device = -1;
+  uint32_t ticket = 0;
+  uint32_t hist_flip = 0;
+  hipStream_t last_stream = nullptr;
+  bool used = false;
+  // speculative binning size: capacity the next forward allocates before it knows its instance count (0 = none)
+  uint32_t recent[4] = {0, 0, 0, 0};
+  int recent_pos = 0;
+  long long hint_override = -1;               // gsr_set_binning_capacity_hint
+  uint32_t last_R = 0;
+};
+static thread_local ThreadCtx g_ctx;
+
+static int ctx_prepare(ThreadCtx& c, hipStream_t stream) {
+  int cur_device = 0;
+  HIP_TRY(hipGetDevice(&cur_device));
+  if (!c.mailbox || cur_device != c.device) {  // first call of this thread, or the thread switched GPUs
+    void* h = nullptr;
+    void* d = nullptr;
+    void* k = nullptr;
+    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipMalloc(&k, 64 + 2 * 4096) != hipSuccess ||
+        hipMemset(k, 0, 64 + 2 * 4096) != hipSuccess)
+      return fail(GSR_ERR_HIP, "cannot allocate the host-mapped mailbox: %s", hipGetErrorString(hipGetLastError()));
+    c.mailbox = static_cast<unsigned long long*>(h);  // (a previous device's 128 bytes stay allocated: switching is rare)
+    c.mailbox_dev = static_cast<unsigned long long*>(d);
+    c.done_counter = static_cast<unsigned long long*>(k);
+    c.device = cur_device;
+    c.ticket = 0;
+    c.hist_flip = 0;
+    c.used = false;
+    *c.mailbox = 0;
+    (void)hipDeviceSynchronize();  // the counter is zero before any stream uses it
+  }
+  if (c.used && stream != c.last_stream) {
+    // this thread's previous forward ran on another stream: its k_preprocess may still be counting into the words
+    HIP_TRY(hipStreamSynchronize(c.last_stream));
+  }
+  c.last_stream = stream;
+  c.used = true;
+  c.ticket = c.ticket == 0xFFFFFFFFu ? 1u : c.ticket + 1u;  // never 0: the mailbox starts at ticket 0
+  return GSR_OK;
+}
+
+// Waits for k_preprocess's (ticket, R) word.  The host polls a page-locked, host-mapped word (no copy engine, no
+// completion interrupt, whose wake-up latency was measured at up to 30 ms on virtualised hosts).  Safety net: stream
+// queries from 60 us on, every 25 us -- seen on this pool (2 of ~60 bench processes): the word does not become visible
+// to the spinning load until a HIP call is made; every such exit is counted and described (gsr_mailbox_slow_path_*).
+static int wait_num_rendered(ThreadCtx& c, hipStream_t stream, uint32_t* R_out) {
+  using clk = std::chrono::steady_clock;
+  const clk::time_point t0 = clk::now();
+  const auto query_period = std::chrono::microseconds(25);
+  clk::time_point next_query = t0 + std::chrono::microseconds(60);
+  for (;;) {
+    const unsigned long long v = __atomic_load_n(c.mailbox, __ATOMIC_ACQUIRE);
+    if ((uint32_t)(v >> 32) == c.ticket) { *R_out = (uint32_t)v; return GSR_OK; }
+    __builtin_ia32_pause();
+    if (clk::now() < next_query) continue;
+    // slow path: notice a faulted or drained stream instead of spinning for ever
+    const hipError_t q = hipStreamQuery(stream);
+    const unsigned long long v1 = __atomic_load_n(c.mailbox, __ATOMIC_ACQUIRE);
+    if (q == hipSuccess) {  // everything enqueued has retired, so the word has been stored
+      unsigned long long v2 = v1;
+      const clk::time_point t1 = clk::now();
+      while ((uint32_t)(v2 >> 32) != c.ticket && clk::now() - t1 < std::chrono::milliseconds(2))
+        v2 = __atomic_load_n(c.mailbox, __ATOMIC_ACQUIRE);  // a store still in flight towards host memory
+      {
+        std::lock_guard<std::mutex> lk(g_slow_mu);
+        g_slow_last.ticket_expected = c.ticket;
+        g_slow_last.ticket_seen_before_query = (uint32_t)(v >> 32);
+        g_slow_last.ticket_seen_after_query = (uint32_t)(v1 >> 32);
+        g_slow_last.elapsed_us = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
+        g_slow_last.first_query_result = (int)q;
+        g_slow_last.visible_at_query = (uint32_t)(v1 >> 32) == c.ticket;
+        g_slow_last.count = (unsigned)(g_mailbox_slow_hits.load() + 1);
+      }
+      const unsigned long long hits = ++g_mailbox_slow_hits;
+      if (hits <= 3 || getenv("GSR_HOST_TRACE"))
+        fprintf(stderr, "[gsr] mailbox slow path #%llu: ticket %u, seen %u before / %u right after hipStreamQuery (=%d), "
+                        "%.1f us after the enqueue: %s\n", hits, c.ticket, (uint32_t)(v >> 32), (uint32_t)(v1 >> 32), (int)q,
+                g_slow_last.elapsed_us, (uint32_t)(v1 >> 32) == c.ticket
+                    ? "word present once a HIP call had been made (late dispatch / late visibility to the spinning load)"
+                    : "word arrived after the stream had drained (store still in flight)");
+      if ((uint32_t)(v2 >> 32) != c.ticket) {
+        (void)hipMemset(c.done_counter, 0, 64);  // do not leave a half-counted launch behind
+        return fail(GSR_ERR_HIP, "instance count was not published");
+      }
+      *R_out = (uint32_t)v2;
+      return GSR_OK;
+    }
+    if (q != hipErrorNotReady) return fail(GSR_ERR_HIP, "stream failed: %s", hipGetErrorString(q));
+    next_query = clk::now() + query_period;
+  }
+}
+
+// scan -> emit -> tile sort -> ranges -> blend for `cnt` instances in the binning blob `bblob` (carved for cnt.cap)
+static int enqueue_binning_and_blend(const FrameParams& fp, GeomState& g, ImageState& im, char* bblob, const Count cnt,
+                                     const float* background, float* out_color, float* out_depth, float* out_acc,
+                                     int debug, hipStream_t stream) {
+  BinningState b = BinningState::carve(bblob, (size_t)cnt.cap);
+  const int tiles = fp.gx * fp.gy;
+  const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
+  const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
+  const bool key16 = tiles <= 65536;  // tile ids fit 16 bits for every image up to 4096 x 4096
+  STAGE(launch_scan_offsets(fp, g, cnt, b.chunk_first, im.ranges, b.tsort.counts, stream));
+  STAGE(launch_emit(fp, g, cnt, b.chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB,
+                    b.inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16,
+                    /*store_pairs=*/!key16, stream));  // 16-bit keys: the pairs are generated inside the first sort pass
+  const EmitFusion ef = {fp, g, cnt, b.chunk_first};
+  // 16-bit keys and at least two passes: the last pass counts the instances of every tile into the zeroed ranges
+  // instead of writing the sorted keys, and a one-workgroup scan turns the counts into ranges; otherwise the range
+  // kernel reads the sorted keys as the reference's identifyTileRanges does
+  static const bool ranges_from_keys = getenv("GSR_RANGES_FROM_KEYS") != nullptr;  // diagnostics / fallback
+  const bool count_ranges = key16 && sort_passes(tile_bits) >= 2 && !ranges_from_keys;
+  STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, cnt, tile_bits, start_in_A,
+                          /*is_depth_sort=*/false, key16, /*first_hist_done=*/true, key16 ? &ef : nullptr,
+                          count_ranges ? reinterpret_cast<uint32_t*>(im.ranges) : nullptr, stream));
+  if (count_ranges)
+    STAGE(launch_ranges_from_counts(im.ranges, tiles, stream));
+  else
+    STAGE(launch_tile_ranges(b.tkeysA, cnt, im.ranges, key16, stream));
+  if (debug) {  // self-check of the binning chain: every list ordered by (depth bits, id)
+    HIP_TRY(launch_verify_sorted_lists(im.ranges, tiles, b.point_list, g.depths, g.total + 4, stream));
+    uint32_t bad = 0;
+    HIP_TRY(hipMemcpyAsync(&bad, g.total + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
+    HIP_TRY(hipStreamSynchronize(stream));
+    if (bad) return fail(GSR_ERR_HIP, "%u adjacent list entries out of (depth, id) order after the sort", bad);
+  }
+  STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
+  return GSR_OK;
+}
 
 int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
                 gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
@@ -175,6 +340,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     HIP_TRY(hipMemsetAsync(out_color, 0, 3 * N * sizeof(float), stream));
     HIP_TRY(hipMemsetAsync(out_depth, 0, N * sizeof(float), stream));
     HIP_TRY(hipMemsetAsync(out_acc, 0, N * sizeof(float), stream));
+    g_ctx.last_R = 0;
     return 0;
   }
   if (!geometry_alloc || !binning_alloc || !image_alloc) return fail(GSR_ERR_INVALID_ARGUMENT, "null allocator");
@@ -198,131 +364,124 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   GeomState g = GeomState::carve(gblob, (size_t)P);
   ImageState im = ImageState::carve(iblob, width, height);
 
-  // R must be known on the host to size the binning blob, where the reference has its blocking
-  // cudaMemcpy (rasterizer_impl.cu:277).  Here the last workgroup of k_preprocess stores (ticket, R) into a
-  // page-locked, host-mapped word and the host polls that word: no copy engine, no completion interrupt
-  // (whose wake-up latency was measured at up to 30 ms on virtualised hosts), and the host gets R as soon as
-  // the first kernel retires -- the per-Gaussian depth sort, which does not depend on R, is already enqueued
-  // behind it and runs while the host sizes and allocates the binning blob.
-  // A host thread is inside this wait for one forward at a time, so the mailbox and the kernel's
-  // "workgroups done" counter (which its last workgroup resets) can be per-thread singletons.  (They, and the
-  // digit-histogram buffers below, assume that the forwards of one host thread on one device are ordered on the
-  // device -- one stream, as the reference's default-stream use -- not issued concurrently on several streams.)
-  static thread_local unsigned long long* mailbox = nullptr;  // host pointer
-  static thread_local unsigned long long* mailbox_dev = nullptr;
-  static thread_local unsigned long long* done_counter = nullptr;  // device: (workgroups done << 40 | sum)
-  static thread_local int mailbox_device = -1;                     // the device the two device pointers belong to
-  static thread_local uint32_t ticket = 0;
-  int cur_device = 0;
-  HIP_TRY(hipGetDevice(&cur_device));
-  if (!mailbox || cur_device != mailbox_device) {  // first call of this thread, or the thread switched GPUs
-    void* h = nullptr;
-    void* d = nullptr;
-    void* c = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipMalloc(&c, 64 + 2 * 4096) != hipSuccess ||
-        hipMemset(c, 0, 64 + 2 * 4096) != hipSuccess)
-      return fail(GSR_ERR_HIP, "cannot allocate the host-mapped mailbox: %s", hipGetErrorString(hipGetLastError()));
-    mailbox = static_cast<unsigned long long*>(h);  // (a previous device's 128 bytes stay allocated: switching is rare)
-    mailbox_dev = static_cast<unsigned long long*>(d);
-    done_counter = static_cast<unsigned long long*>(c);
-    mailbox_device = cur_device;
-    ticket = 0;
-    *mailbox = 0;
-    (void)hipDeviceSynchronize();  // the counter is zero before any stream uses it
+  // The instance count R sizes the binning blob, where the reference has its blocking cudaMemcpy
+  // (rasterizer_impl.cu:277).  The last workgroup of k_preprocess stores (ticket, R) into a page-locked, host-mapped
+  // word that the host polls (wait_num_rendered).
+  //   * synchronous forward (a thread's first forward, debug forwards, GSR_SYNC_FORWARD=1): the host waits for the
+  //     word right after enqueueing k_preprocess and the depth sort -- which does not depend on R and runs while the
+  //     host sizes and allocates the blob -- and then enqueues the rest with the exact count;
+  //   * speculative forward (the steady state): the blob is allocated for a capacity predicted from this thread's
+  //     recent forwards, EVERYTHING is enqueued at once with the kernels reading R from device memory (Count), and the
+  //     host reads the word only at the very end, when it has long been written: no host wait, and the GPU never
+  //     waits for the host.  If R exceeds the capacity the kernels have clamped to it (in-bounds garbage); the
+  //     host then allocates an exact blob and enqueues the binning chain again -- the only cost of a misprediction.
+  ThreadCtx& c = g_ctx;
+  {
+    const int rc = ctx_prepare(c, stream);
+    if (rc != GSR_OK) return rc;
   }
-  ticket = ticket == 0xFFFFFFFFu ? 1u : ticket + 1u;  // never 0: the mailbox starts at ticket 0
   // Digit histograms of the depth sort, counted by k_preprocess: two library-owned [4][256] buffers behind the
   // counter, used alternately -- a forward counts into one (zero on entry) and clears the other for the next
   // forward of this thread, so a call that ends early never leaves a dirty buffer in the way.
   // GSR_DEPTH_HIST_PASS=1 restores the sort's own histogram pass (k_sort_hist_all).
   static const bool env_hist_pass = getenv("GSR_DEPTH_HIST_PASS") != nullptr;
   const bool own_hist_pass = env_hist_pass || !preprocess_counts_depth_digits(fp, shs, colors_precomp);
-  uint32_t* const ghist2 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(done_counter) + 64);
-  static thread_local uint32_t hist_flip = 0;  // (not the ticket: its wrap-around skips 0 and would repeat a parity)
-  if (!own_hist_pass) hist_flip ^= 1u;  // only a call that uses the pair advances it (the other buffer is clean)
-  uint32_t* const ghist_acc = own_hist_pass ? nullptr : ghist2 + 1024 * hist_flip;
-  uint32_t* const ghist_clear = own_hist_pass ? nullptr : ghist2 + 1024 * (hist_flip ^ 1u);
+  uint32_t* const ghist2 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c.done_counter) + 64);
+  if (!own_hist_pass) c.hist_flip ^= 1u;  // only a call that uses the pair advances it (the other buffer is clean)
+  uint32_t* const ghist_acc = own_hist_pass ? nullptr : ghist2 + 1024 * c.hist_flip;
+  uint32_t* const ghist_clear = own_hist_pass ? nullptr : ghist2 + 1024 * (c.hist_flip ^ 1u);
   STAGE(launch_preprocess(fp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
-                          projmatrix, cam_pos, g, radii, done_counter, mailbox_dev, ticket, ghist_acc, ghist_clear, stream));
+                          projmatrix, cam_pos, g, radii, c.done_counter, c.mailbox_dev, c.ticket, ghist_acc, ghist_clear,
+                          stream));
   STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, ghist_acc, stream));
   if (debug) STAGE(launch_point_offsets(fp, g, stream));  // the reference's array, for the views only
+
+  static const bool env_sync = getenv("GSR_SYNC_FORWARD") != nullptr;
+  static const bool host_trace = getenv("GSR_HOST_TRACE") != nullptr;  // diagnostics: host-side waits
+  uint32_t hint = 0;
+  if (c.hint_override >= 0) {
+    hint = (uint32_t)c.hint_override;
+    c.hint_override = -1;
+  } else {
+    for (int k = 0; k < 4; k++) hint = c.recent[k] > hint ? c.recent[k] : hint;
+    if (hint) hint = (uint32_t)std::min<unsigned long long>(0x7fffffffull, (unsigned long long)hint * 5 / 4 + 65536);
+  }
+  const bool speculate = !debug && !env_sync && hint > 0;
+  const std::chrono::steady_clock::time_point t_enq = std::chrono::steady_clock::now();
   uint32_t R_host = 0;
-  const std::chrono::steady_clock::time_point t_enqueued = std::chrono::steady_clock::now();
-  {
-    using clk = std::chrono::steady_clock;
-    const clk::time_point t0 = t_enqueued;
-    // Safety net: stream queries from 60 us on, every 25 us.  Seen on this pool (2 of ~60 bench processes): the
-    // word never becomes visible to the spinning load and only the query path below returns -- with a 2 ms period
-    // that cost 1.3 ms of GPU idle per forward, with 25 us it costs at most the tail of one period after the
-    // stream has drained.  (gsr_mailbox_slow_path_hits() counts these exits; bench.py reports it.)
-    const auto query_period = std::chrono::microseconds(25);
-    clk::time_point next_query = t0 + std::chrono::microseconds(60);
-    for (;;) {
-      const unsigned long long v = __atomic_load_n(mailbox, __ATOMIC_ACQUIRE);
-      if ((uint32_t)(v >> 32) == ticket) { R_host = (uint32_t)v; break; }
-      __builtin_ia32_pause();
-      if (clk::now() < next_query) continue;
-      // slow path: notice a faulted or drained stream instead of spinning for ever
-      const hipError_t q = hipStreamQuery(stream);
-      if (q == hipSuccess) {  // everything enqueued has retired, so the word has been stored
-        const unsigned long long v2 = __atomic_load_n(mailbox, __ATOMIC_ACQUIRE);
-        if ((uint32_t)(v2 >> 32) != ticket) {
-          (void)hipMemset(done_counter, 0, 64);  // do not leave a half-counted launch behind
-          return fail(GSR_ERR_HIP, "instance count was not published");
-        }
-        R_host = (uint32_t)v2;
-        g_mailbox_slow_hits++;
-        break;
-      }
-      if (q != hipErrorNotReady) return fail(GSR_ERR_HIP, "stream failed: %s", hipGetErrorString(q));
-      next_query = clk::now() + query_period;
+  int key = 0;  // what the caller passes back to gsr_backward: the capacity the binning blob was carved for
+  if (!speculate) {
+    const int rc = wait_num_rendered(c, stream, &R_host);
+    if (rc != GSR_OK) return rc;
+    if (R_host > 0x7fffffffu) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31 splat instances");
+    const std::chrono::steady_clock::time_point ta = std::chrono::steady_clock::now();
+    char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes((int)R_host));
+    if (host_trace)
+      fprintf(stderr, "[gsr] synchronous forward: R=%u, waited %.1f us, binning alloc %.1f us\n", R_host,
+              std::chrono::duration<double, std::micro>(ta - t_enq).count(),
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count());
+    if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
+    key = (int)R_host;
+    const int rc2 = enqueue_binning_and_blend(fp, g, im, bblob, Count{nullptr, key}, background, out_color, out_depth,
+                                              out_acc, debug, stream);
+    if (rc2 != GSR_OK) return rc2;
+  } else {
+    key = (int)hint;
+    char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
+    if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
+    int rc = enqueue_binning_and_blend(fp, g, im, bblob, Count{g.total, key}, background, out_color, out_depth, out_acc,
+                                       debug, stream);
+    if (rc != GSR_OK) return rc;
+    const std::chrono::steady_clock::time_point tw = std::chrono::steady_clock::now();
+    rc = wait_num_rendered(c, stream, &R_host);
+    if (rc != GSR_OK) return rc;
+    if (host_trace)
+      fprintf(stderr, "[gsr] speculative forward: capacity %d, R=%u, enqueue %.1f us, then waited %.1f us\n", key, R_host,
+              std::chrono::duration<double, std::micro>(tw - t_enq).count(),
+              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count());
+    ++g_speculative_forwards;
+    if (R_host > 0x7fffffffu) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31 splat instances");
+    if (R_host > (uint32_t)key) {  // misprediction: the clamped results are discarded, the chain runs again, exact
+      ++g_speculation_overflows;
+      key = (int)R_host;
+      // k_scan_offsets runs a second time: its tile ticket and look-back status words (cleared by k_preprocess for
+      // the first run) must be zero again
+      HIP_TRY(hipMemsetAsync(g.dsort.tickets() + 4, 0, sizeof(uint32_t), stream));
+      HIP_TRY(hipMemsetAsync(g.dsort.scan_status(), 0, sizeof(unsigned long long) * (((size_t)P + SCAN_TILE - 1) / SCAN_TILE),
+                             stream));
+      bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
+      if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
+      rc = enqueue_binning_and_blend(fp, g, im, bblob, Count{nullptr, key}, background, out_color, out_depth, out_acc,
+                                     debug, stream);
+      if (rc != GSR_OK) return rc;
     }
   }
-  if (R_host > 0x7fffffffu) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31 splat instances");
-  const int R = (int)R_host;
+  c.recent[c.recent_pos] = R_host;
+  c.recent_pos = (c.recent_pos + 1) & 3;
+  c.last_R = R_host;
+  return key;
+}
 
-  static const bool host_trace = getenv("GSR_HOST_TRACE") != nullptr;  // diagnostics: host-side waits
-  const std::chrono::steady_clock::time_point ta = std::chrono::steady_clock::now();
-  char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(R));
-  if (host_trace) {
-    const std::chrono::steady_clock::time_point tb = std::chrono::steady_clock::now();
-    fprintf(stderr, "[gsr] R=%d wait %.1f us, binning alloc %.1f us\n", R,
-            std::chrono::duration<double, std::micro>(ta - t_enqueued).count(),
-            std::chrono::duration<double, std::micro>(tb - ta).count());
-  }
-  if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
-  BinningState b = BinningState::carve(bblob, (size_t)R);
-
-  const int tiles = fp.gx * fp.gy;
-  const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
-  const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
-  const bool key16 = tiles <= 65536;  // tile ids fit 16 bits for every image up to 4096 x 4096
-  STAGE(launch_scan_offsets(fp, g, R, b.chunk_first, im.ranges, b.tsort.counts, stream));
-  STAGE(launch_emit(fp, g, R, b.chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB,
-                    b.inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16,
-                    /*store_pairs=*/!key16, stream));  // 16-bit keys: the pairs are generated inside the first sort pass
-  const EmitFusion ef = {fp, g, R, b.chunk_first};
-  // 16-bit keys and at least two passes: the last pass counts the instances of every tile into the zeroed ranges
-  // instead of writing the sorted keys, and a one-workgroup scan turns the counts into ranges; otherwise the range
-  // kernel reads the sorted keys as the reference's identifyTileRanges does
-  static const bool ranges_from_keys = getenv("GSR_RANGES_FROM_KEYS") != nullptr;  // diagnostics / fallback
-  const bool count_ranges = key16 && sort_passes(tile_bits) >= 2 && !ranges_from_keys;
-  STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, R, tile_bits, start_in_A,
-                          /*is_depth_sort=*/false, key16, /*first_hist_done=*/true, key16 ? &ef : nullptr,
-                          count_ranges ? reinterpret_cast<uint32_t*>(im.ranges) : nullptr, stream));
-  if (count_ranges)
-    STAGE(launch_ranges_from_counts(im.ranges, tiles, stream));
-  else
-    STAGE(launch_tile_ranges(b.tkeysA, R, im.ranges, key16, stream));
-  STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
-  return R;
+int gsr_last_num_rendered(void) { return (int)g_ctx.last_R; }
+long long gsr_set_binning_capacity_hint(long long capacity) {
+  const long long prev = g_ctx.hint_override;
+  g_ctx.hint_override = capacity < 0 ? -1 : (capacity > 0x7fffffffll ? 0x7fffffffll : capacity);
+  if (capacity == 0) g_ctx.recent[0] = g_ctx.recent[1] = g_ctx.recent[2] = g_ctx.recent[3] = 0;
+  return prev;
+}
+unsigned long long gsr_speculative_forwards(void) { return g_speculative_forwards.load(); }
+unsigned long long gsr_speculation_overflows(void) { return g_speculation_overflows.load(); }
+int gsr_mailbox_slow_path_last(gsr_mailbox_event* out) {
+  if (!out) return fail(GSR_ERR_INVALID_ARGUMENT, "null pointer");
+  std::lock_guard<std::mutex> lk(g_slow_mu);
+  *out = g_slow_last;
+  return GSR_OK;
 }
 
 int gsr_set_reference_rects(int on) { return reference_rects_flag().exchange(on != 0 ? 1 : 0); }
 int gsr_reference_rects(void) { return reference_rects_flag().load(); }
 
-unsigned long long gsr_mailbox_slow_path_hits(void) { return g_mailbox_slow_hits; }
+unsigned long long gsr_mailbox_slow_path_hits(void) { return g_mailbox_slow_hits.load(); }
 
 int gsr_backward(int P, int D, int M, int R, const float* background, int width, int height, const float* means3D,
                  const float* shs, const float* colors_precomp, const float* scales, float scale_modifier,
@@ -497,6 +656,7 @@ int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out) {
   out->point_offsets = g.point_offsets;
   out->clamped = g.clamped;
   out->depth_order = g.order;
+  out->num_rendered = g.total;
   return GSR_OK;
 }
 

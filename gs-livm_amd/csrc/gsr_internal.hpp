@@ -2,6 +2,7 @@
 // of libgsraster_hip.so (gfx950 only).  Not part of the public ABI (include/gsraster.h).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <atomic>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -202,6 +203,20 @@ struct BinningState {
   }
 };
 
+// Number of splat instances as the binning kernels see it.  `dev == nullptr`: the host knows it (`cap` IS the count:
+// the synchronous forward).  Otherwise the host has sized grids and buffers for `cap` instances WITHOUT waiting for the
+// count (api.hip, speculative forward) and every kernel reads it from device memory, clamped to `cap` -- an overflowing
+// frame then produces in-bounds garbage that the host discards and redoes with the exact count.
+struct Count {
+  const uint32_t* dev;
+  int cap;
+  __device__ __forceinline__ int get() const {
+    if (!dev) return cap;
+    const uint32_t v = __builtin_nontemporal_load(dev);
+    return v < (uint32_t)cap ? (int)v : cap;
+  }
+};
+
 struct FrameParams {
   int P, D, M, W, H, gx, gy;
   float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
@@ -217,16 +232,16 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
                              unsigned long long* publish, uint32_t ticket, uint32_t* ghist_acc, uint32_t* ghist_clear,
                              hipStream_t s);
 hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
-hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint2* ranges,
+hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint2* ranges,
                                uint32_t* counts0, hipStream_t s);
-hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
+hipError_t launch_emit(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint32_t* tkeys_out,
                        uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_mask0, bool key16,
                        bool store_pairs, hipStream_t s);
 // what k_emit_scatter (the tile sort's first pass with the pairs generated in place) needs from the emitter's side
 struct EmitFusion {
   FrameParams fp;
   GeomState g;
-  int R;
+  Count R;
   const uint32_t* chunk_first;
 };
 hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_t* vals_out, int nbits0,
@@ -237,13 +252,15 @@ hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningStat
 // Stable LSD radix sort of n (u32, u32) pairs on key bits [0, end_bit); buffers ping-pong between
 // (keysA, valsA) and (keysB, valsB), starting in A when start_in_A.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
-                             int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
+                             Count n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
                              bool first_hist_done, const EmitFusion* fused_first_pass, uint32_t* key_count,
                              hipStream_t s);
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
                              int n, const uint32_t* ghist, hipStream_t s);
 hipError_t launch_ranges_from_counts(uint2* ranges, int T, hipStream_t s);
-hipError_t launch_tile_ranges(const uint32_t* tile_ids, int R, uint2* ranges, bool key16, hipStream_t s);
+hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t* point_list, const float* depths,
+                                      uint32_t* violations, hipStream_t s);
+hipError_t launch_tile_ranges(const uint32_t* tile_ids, Count R, uint2* ranges, bool key16, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, hipStream_t s);
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
@@ -295,12 +312,15 @@ enum KernelId {
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);
-extern bool g_prof_on;
-extern unsigned long long g_prof_mask;  // bit i: kernel id i is recorded
+extern std::atomic<bool> g_prof_on;
+extern std::atomic<unsigned long long> g_prof_mask;  // bit i: kernel id i is recorded
 struct ProfScope {  // records a start/stop event pair around the launches in its scope while profiling is on
   hipStream_t s;
   bool on;
-  ProfScope(int id, hipStream_t st) : s(st), on(g_prof_on && ((g_prof_mask >> id) & 1ull)) { if (on) prof_begin(id, s); }
+  ProfScope(int id, hipStream_t st)
+      : s(st), on(g_prof_on.load(std::memory_order_relaxed) && ((g_prof_mask.load(std::memory_order_relaxed) >> id) & 1ull)) {
+    if (on) prof_begin(id, s);
+  }
   ~ProfScope() { if (on) prof_end(s); }
 };
 

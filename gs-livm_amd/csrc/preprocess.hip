@@ -488,13 +488,14 @@ __global__ __launch_bounds__(1024) void k_point_offsets(const int P, const uint3
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned long long SC_GLOBAL = 2ull << 32, SC_LOCAL = 1ull << 32;
 
-__global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp, GeomState g, const int R,
+__global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp, GeomState g, const Count cnt,
                                                             uint32_t* __restrict__ chunk_first,
                                                             uint2* __restrict__ ranges,
                                                             uint32_t* __restrict__ counts0, const size_t ncounts0) {
   __shared__ uint32_t wtot[PRE_BLOCK / 64];
   __shared__ uint32_t s_tile, s_prefix;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int R = cnt.get();  // min(num_rendered, capacity): slots beyond the capacity are never emitted (api.hip)
   // side job: (0, 0) for the tiles no instance lands in
   for (int t = blockIdx.x * PRE_BLOCK + tid; t < fp.gx * fp.gy; t += gridDim.x * PRE_BLOCK)
     ranges[t] = make_uint2(0u, 0u);
@@ -571,9 +572,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
     if (i0 + k < fp.P && n[k]) {
       const uint32_t end = off + n[k];
       g.slotinfo[id[k]] = make_uint2(off, rect[k]);
-      for (uint32_t c = (off + EMIT_CHUNK - 1) / EMIT_CHUNK; (unsigned long long)c * EMIT_CHUNK < end; c++)
+      const uint32_t end_c = end < (uint32_t)R ? end : (uint32_t)R;  // (R < num_rendered only in an overflowed frame)
+      for (uint32_t c = (off + EMIT_CHUNK - 1) / EMIT_CHUNK; (unsigned long long)c * EMIT_CHUNK < end_c; c++)
         chunk_first[c] = (uint32_t)(i0 + k);
-      if (end == (uint32_t)R) chunk_first[last_chunk] = (uint32_t)(i0 + k);
+      if (off < (uint32_t)R && end >= (uint32_t)R) chunk_first[last_chunk] = (uint32_t)(i0 + k);
     }
     off += n[k];
   }
@@ -642,7 +644,7 @@ __device__ __forceinline__ void emit_walk8(uint32_t t0, uint32_t c1, int S, cons
 // the unsorted pairs are never written to or read back from HBM (2 x 6 bytes per instance).  The digit counts the
 // scatter needs were accumulated by the count-only emitter (k_emit<K, false>) and scanned in between.
 template <bool ARANK>
-__global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, GeomState g, const int R,
+__global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, GeomState g, const Count cnt,
                                                       const uint32_t* __restrict__ chunk_first,
                                                       uint16_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                       const int nbits0, const uint32_t* __restrict__ counts,
@@ -657,6 +659,8 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, Geom
   __shared__ SMem sm;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int tile = blockIdx.x;
+  const int R = cnt.get();
+  if ((size_t)tile * TSORT_TILE >= (size_t)R) return;  // (grid sized for the capacity)
   uint32_t tk[2][8], iv[2][8];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
@@ -705,7 +709,7 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, Geom
 
 // STORE = false: count-only emitter in front of k_emit_scatter (digit counts + inst_flag reset, no pair stores)
 template <typename K, bool STORE>
-__global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g, const int R,
+__global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g, const Count cnt,
                                               const uint32_t* __restrict__ chunk_first,
                                               K* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out,
                                               uint8_t* __restrict__ inst_flag, uint32_t* __restrict__ counts0,
@@ -713,6 +717,8 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
   __shared__ EmitStage st;
   __shared__ uint32_t hist[256];  // digit counts of the tile sort's FIRST pass for this workgroup's 2048 slots
   const int tid = threadIdx.x;
+  const int R = cnt.get();
+  if ((size_t)blockIdx.x * EMIT_CHUNK >= (size_t)R) return;  // (grid sized for the capacity)
   hist[tid] = 0;
   const uint32_t c0 = (uint32_t)blockIdx.x * EMIT_CHUNK;
   const uint32_t c1 = c0 + EMIT_CHUNK < (uint32_t)R ? c0 + EMIT_CHUNK : (uint32_t)R;
@@ -1207,21 +1213,21 @@ hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t 
   return hipGetLastError();
 }
 
-hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint2* ranges,
+hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint2* ranges,
                                uint32_t* counts0, hipStream_t s) {
-  const size_t ncounts0 = (size_t)((R + TSORT_TILE - 1) / TSORT_TILE) * 256;
+  const size_t ncounts0 = (size_t)((R.cap + TSORT_TILE - 1) / TSORT_TILE) * 256;
   ProfScope ps(K_SCAN_OFFSETS, s);
   hipLaunchKernelGGL(k_scan_offsets, dim3((fp.P + SCAN_TILE - 1) / SCAN_TILE), dim3(PRE_BLOCK), 0, s, fp, g, R,
                      chunk_first, ranges, counts0, ncounts0);
   return hipGetLastError();
 }
 
-hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chunk_first, uint32_t* tkeys_out,
+hipError_t launch_emit(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint32_t* tkeys_out,
                        uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_mask0, bool key16,
                        bool store_pairs, hipStream_t s) {
-  if (R <= 0) return hipSuccess;
+  if (R.cap <= 0) return hipSuccess;
   ProfScope ps(K_EMIT, s);
-  const dim3 grid((R + EMIT_CHUNK - 1) / EMIT_CHUNK);
+  const dim3 grid((R.cap + EMIT_CHUNK - 1) / EMIT_CHUNK);
   if (key16 && store_pairs)
     hipLaunchKernelGGL((k_emit<uint16_t, true>), grid, dim3(256), 0, s, fp, g, R, chunk_first,
                        reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_mask0);
@@ -1238,7 +1244,7 @@ hipError_t launch_emit(const FrameParams& fp, GeomState g, int R, uint32_t* chun
 hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_t* vals_out, int nbits0,
                                const uint32_t* counts, const uint32_t* chunk_base, const uint32_t* digit_total,
                                bool arank, hipStream_t s) {
-  const dim3 grid((ef.R + TSORT_TILE - 1) / TSORT_TILE);
+  const dim3 grid((ef.R.cap + TSORT_TILE - 1) / TSORT_TILE);
   if (arank)
     hipLaunchKernelGGL(k_emit_scatter<true>, grid, dim3(256), 0, s, ef.fp, ef.g, ef.R, ef.chunk_first, keys_out, vals_out,
                        nbits0, counts, chunk_base, digit_total);

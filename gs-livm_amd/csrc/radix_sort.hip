@@ -26,6 +26,7 @@
 //   (DESIGN.md "Tried and rejected"), for the 10^6-pair sort it replaces 16 launches by 5.
 // Every step is order-preserving (stable); no float atomics.
 #include <cstdlib>
+#include <mutex>
 
 #include "gsr_internal.hpp"
 #include "sort_core.hpp"
@@ -36,10 +37,11 @@ namespace gsr {
 // Per-tile digit counts with LDS integer atomics (order-independent, so still deterministic): three
 // instructions per key instead of a ballot match; neighbouring keys rarely share a digit in either sort.
 template <typename K, int TILE>
-__global__ __launch_bounds__(256) void k_sort_hist(const K* __restrict__ keys, int n, int shift, int nbits,
+__global__ __launch_bounds__(256) void k_sort_hist(const K* __restrict__ keys, const Count cnt, int shift, int nbits,
                                                    uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[256];
   const int tid = threadIdx.x;
+  const int n = cnt.get();  // (tiles beyond it leave zero counts: the scans run over the capacity's tiles)
   const uint32_t mask = (1u << nbits) - 1u;
   hist[tid] = 0;
   __syncthreads();
@@ -162,30 +164,69 @@ __global__ __launch_bounds__(64) void k_probe_lds_atomic_order(uint32_t* __restr
 // Once per process: may k_sort_scatter rank with returning LDS atomics (see ARANK)?  GSR_SORT_BALLOT_RANK=1 in
 // the environment forces the ballot variant.
 static bool lds_atomic_rank_ok(hipStream_t s) {
-  static int state = -1;
-  if (state >= 0) return state == 1;
-  state = 0;
+  // decided once per DEVICE, under a lock (the reference calls the rasterizer from several host threads); a debug
+  // forward additionally verifies the order of every sorted list it produces (k_verify_sorted_lists)
+  static std::mutex mu;
+  static int state[64];
+  static bool init = false;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!init) {
+    for (int& v : state) v = -1;
+    init = true;
+  }
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return false;
+  if (state[dev] >= 0) return state[dev] == 1;
+  state[dev] = 0;
   if (getenv("GSR_SORT_BALLOT_RANK")) return false;
   uint32_t* d = nullptr;
   uint32_t h = 0;
   if (hipMalloc(reinterpret_cast<void**>(&d), sizeof(uint32_t)) != hipSuccess) return false;
   hipLaunchKernelGGL(k_probe_lds_atomic_order, dim3(1), dim3(64), 0, s, d);
   if (hipStreamSynchronize(s) == hipSuccess && hipMemcpy(&h, d, sizeof(h), hipMemcpyDeviceToHost) == hipSuccess)
-    state = h == 1u ? 1 : 0;
+    state[dev] = h == 1u ? 1 : 0;
   (void)hipFree(d);
-  return state == 1;
+  return state[dev] == 1;
+}
+
+// Debug forwards only: every tile's list must be ordered by (depth bits, Gaussian id) -- the order a stable sort of
+// the reference's 64-bit keys produces.  Cheap self-check of the whole binning chain,
+// in particular of the returning-LDS-atomic ranking whose lane order the ISA manual does not document.
+__global__ __launch_bounds__(256) void k_verify_sorted_lists(const uint2* __restrict__ ranges, const int T,
+                                                             const uint32_t* __restrict__ point_list,
+                                                             const float* __restrict__ depths,
+                                                             uint32_t* __restrict__ violations) {
+  const int tile = blockIdx.x;
+  if (tile >= T) return;
+  const uint2 r = ranges[tile];
+  uint32_t bad = 0;
+  for (uint32_t i = r.x + 1 + threadIdx.x; i < r.y; i += 256) {
+    const uint32_t a = point_list[i - 1], b = point_list[i];
+    const uint32_t da = __float_as_uint(depths[a]), db = __float_as_uint(depths[b]);
+    if (da > db || (da == db && a >= b)) bad++;
+  }
+  if (bad) atomicAdd(violations, bad);
+}
+
+hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t* point_list, const float* depths,
+                                      uint32_t* violations, hipStream_t s) {
+  hipError_t e = hipMemsetAsync(violations, 0, sizeof(uint32_t), s);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_verify_sorted_lists, dim3(T), dim3(256), 0, s, ranges, T, point_list, depths, violations);
+  return hipGetLastError();
 }
 
 // The pairs start in (keysA, valsA) when start_in_A, else in (keysB, valsB); passes alternate.  The caller
 // picks start_in_A = (passes even) so the result always lands in (keysA, valsA).
 template <typename K>
-static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t* valsB, SortScratch sc, int n,
+static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t* valsB, SortScratch sc, Count cnt,
                                   int end_bit, bool start_in_A, bool is_depth_sort, bool first_hist_done,
                                   const EmitFusion* ef, uint32_t* key_count, hipStream_t s) {
   const int kb = is_depth_sort ? (int)K_DSORT_HIST - (int)K_SORT_HIST : 0;  // profiler ids of this sort
   // tile geometry of the instance sort (both key widths use the same today; see TSORT_TILE)
   constexpr int TT = sizeof(K) == 2 ? TSORT_TILE : SORT_TILE, NWV = sizeof(K) == 2 ? TSORT_WAVES : 4;
   if (sizeof(K) != 2) first_hist_done = false;  // the emitter counts per TSORT_TILE slots
+  const int n = cnt.cap;  // grids and scratch cover the capacity; the kernels read the count itself (Count)
   const int ntiles = (n + TT - 1) / TT;
   const int nchunks = (ntiles + SORT_CHUNK - 1) / SORT_CHUNK;
   const int passes = sort_passes(end_bit);
@@ -200,7 +241,7 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
     const int shift = nbits * p;
     if (!(p == 0 && first_hist_done)) {  // the emitter already left the first pass's counts in sc.counts
       ProfScope ps(K_SORT_HIST + kb, s);
-      hipLaunchKernelGGL((k_sort_hist<K, TT>), dim3(ntiles), dim3(256), 0, s, kin, n, shift, nbits, sc.counts);
+      hipLaunchKernelGGL((k_sort_hist<K, TT>), dim3(ntiles), dim3(256), 0, s, kin, cnt, shift, nbits, sc.counts);
     }
     {
       ProfScope ps(K_SORT_SCAN_CHUNKS + kb, s);
@@ -220,20 +261,20 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
       ProfScope ps(K_SORT_SCATTER + kb, s);
       if (arank)
         hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT, true>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout,
-                           vout, n, shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
+                           vout, cnt, shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr, key_count);
       else
         hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT, true>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout,
-                           vout, n, shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
+                           vout, cnt, shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr, key_count);
     } else {
       ProfScope ps(K_SORT_SCATTER + kb, s);
       if (arank)
-        hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, n,
+        hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, cnt,
                            shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
       else
-        hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, n,
+        hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, cnt,
                            shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
     }
@@ -245,10 +286,10 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
 // key16: the keys are 16-bit (tile ids of images with <= 65536 tiles): a quarter less traffic per pass; the
 // buffers are the same allocations, viewed as uint16_t.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
-                             int n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
+                             Count n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
                              bool first_hist_done, const EmitFusion* fused_first_pass, uint32_t* key_count,
                              hipStream_t s) {
-  if (n <= 0) return hipSuccess;
+  if (n.cap <= 0) return hipSuccess;
   if (key16)
     return sort_pairs_impl<uint16_t>(reinterpret_cast<uint16_t*>(keysA), valsA, reinterpret_cast<uint16_t*>(keysB),
                                      valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done, fused_first_pass,
@@ -273,12 +314,12 @@ static void depth_sort_passes(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB,
     uint32_t* kout = inA ? keysB : keysA;
     uint32_t* vout = inA ? valsB : valsA;
     if (arank)
-      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true, NW, TILE>), dim3(ntiles), dim3(64 * NW), 0, s, kin, vin, kout, vout, n,
-                         8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, ghist + 256 * p,
+      hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, true, NW, TILE>), dim3(ntiles), dim3(64 * NW), 0, s, kin, vin, kout, vout,
+                         (Count{nullptr, n}), 8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, ghist + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     else
       hipLaunchKernelGGL((k_sort_scatter<uint32_t, true, false, NW, TILE>), dim3(ntiles), dim3(64 * NW), 0, s, kin, vin, kout, vout,
-                         n, 8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, ghist + 256 * p,
+                         (Count{nullptr, n}), 8 * p, 8, (const uint32_t*)nullptr, (const uint32_t*)nullptr, ghist + 256 * p,
                          sc.status(p, ntiles), sc.tickets() + p);
     inA = !inA;
   }
@@ -308,8 +349,9 @@ hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
 // reference's cudaMemset at :311 -- here a side job of k_scan_offsets).  Every thread owns 16 bytes of sorted
 // keys (8 x u16 or 4 x u32) plus the key before them, so the pass over the keys runs at streaming rate.
 template <typename K>
-__global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys, int L, uint2* __restrict__ ranges) {
+__global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys, const Count cnt, uint2* __restrict__ ranges) {
   constexpr int PER = 16 / (int)sizeof(K);
+  const int L = cnt.get();
   const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * PER;
   if (i0 >= (size_t)L) return;
   uint32_t k[PER];
@@ -374,14 +416,14 @@ hipError_t launch_ranges_from_counts(uint2* ranges, int T, hipStream_t s) {
   return hipGetLastError();
 }
 
-hipError_t launch_tile_ranges(const uint32_t* keys, int R, uint2* ranges, bool key16, hipStream_t s) {
-  if (R <= 0) return hipSuccess;
+hipError_t launch_tile_ranges(const uint32_t* keys, Count R, uint2* ranges, bool key16, hipStream_t s) {
+  if (R.cap <= 0) return hipSuccess;
   ProfScope ps(K_TILE_RANGES, s);
   if (key16)
-    hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((R + 2047) / 2048), dim3(256), 0, s,
+    hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((R.cap + 2047) / 2048), dim3(256), 0, s,
                        reinterpret_cast<const uint16_t*>(keys), R, ranges);
   else
-    hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((R + 1023) / 1024), dim3(256), 0, s, keys, R, ranges);
+    hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((R.cap + 1023) / 1024), dim3(256), 0, s, keys, R, ranges);
   return hipGetLastError();
 }
 

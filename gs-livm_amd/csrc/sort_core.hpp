@@ -239,7 +239,7 @@ template <typename K, bool LB, bool ARANK, int NW, int TILE, bool COUNT = false>
 __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ keys_in,
                                                       const uint32_t* __restrict__ vals_in,
                                                       K* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                      int n, int shift, int nbits, const uint32_t* __restrict__ counts,
+                                                      const Count cnt, int shift, int nbits, const uint32_t* __restrict__ counts,
                                                       const uint32_t* __restrict__ chunk_base,
                                                       const uint32_t* __restrict__ digit_total,
                                                       uint32_t* __restrict__ status, uint32_t* __restrict__ ticket,
@@ -247,6 +247,8 @@ __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ 
   constexpr int WTILE = TILE / NW, NSTEP = WTILE / 64;
   __shared__ ScatterLds<K, NW, TILE> L;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int n = cnt.get();
+  if (!LB && (size_t)blockIdx.x * TILE >= (size_t)n) return;  // (grid sized for the capacity: nothing in this tile)
   int tile = blockIdx.x;
   if (LB) {
     __shared__ int s_tile;

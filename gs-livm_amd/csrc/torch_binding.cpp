@@ -51,9 +51,14 @@ void check(int code, const char* what) {
 }
 
 // Allocator callback: replaces resizeFunctional (rasterize_points.cu:36-44).
+// The binning blob's callback can come a second time within one forward (gsr_forward, speculative path, when the
+// predicted capacity was too small): the tensor is then replaced, not resized -- resize_ would copy the old contents.
 char* resize_blob(void* ctx, size_t bytes) {
   auto* t = static_cast<torch::Tensor*>(ctx);
-  t->resize_({static_cast<long long>(bytes)});
+  if (t->numel() != 0)
+    *t = torch::empty({static_cast<long long>(bytes)}, t->options());
+  else
+    t->resize_({static_cast<long long>(bytes)});
   return reinterpret_cast<char*>(t->data_ptr());
 }
 
@@ -294,6 +299,9 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
   m.def("RasterizeGaussiansCUDA", &RasterizeGaussiansCUDA);
   m.def("RasterizeGaussiansBackwardCUDA", &RasterizeGaussiansBackwardCUDA);
   m.def("markVisible", [](torch::Tensor a, torch::Tensor b, torch::Tensor c) { return markVisible(a, b, c); });
+  // exact instance count of this thread's last forward (RasterizeGaussiansCUDA's first element is the binning key:
+  // the capacity the binning blob was carved for -- equal to the count after a synchronous forward)
+  m.def("last_num_rendered", []() { return gsr_last_num_rendered(); });
   py::class_<GaussianRasterizationSettings>(m, "GaussianRasterizationSettings")
       .def(py::init([](int h, int w, float tx, float ty, torch::Tensor bg, float sm, torch::Tensor view,
                        torch::Tensor proj, int deg, torch::Tensor cam, bool pre) {

@@ -51,9 +51,25 @@ typedef char* (*gsr_alloc_fn)(void* ctx, size_t bytes);
  *   prefiltered / debug: accepted for signature parity; prefiltered has no effect in the
  *   reference forward either; debug != 0 synchronises the
  *   stream after every stage and reports kernel errors (auxiliary.h:146-154).
- * Returns num_rendered (R >= 0), or a negative gsr_status.  Like the reference this
- * call blocks the host once (R must be known to size the binning blob,
- * rasterizer_impl.cu:277). */
+ * Returns, on success, the BINNING KEY (>= 0): the number to pass to gsr_backward as `R` (and to
+ * gsr_binning_view_of) together with the three blobs -- the instance capacity the binning blob was carved for;
+ * a negative gsr_status on failure.
+ *   - Synchronous forward (a host thread's first forward, every debug != 0 forward, GSR_SYNC_FORWARD=1): the
+ *     host waits for num_rendered where the reference has its blocking cudaMemcpy
+ *     (rasterizer_impl.cu:277), sizes the binning blob exactly, and the key IS num_rendered.
+ *   - Speculative forward (the steady state): the binning blob is allocated for a capacity predicted
+ *     from the calling thread's recent forwards (5/4 of the largest of the last four + 64 Ki), every
+ *     kernel is enqueued at once and reads num_rendered from device memory, and the host looks at
+ *     the count only after the last launch, when it has long been written -- no host wait, no GPU
+ *     idle.  The key is the capacity (>= num_rendered).  If num_rendered exceeded the capacity
+ *     the binning allocator is called a SECOND time (exact size; the first allocation may be
+ *     released) and the binning chain is enqueued again; results are identical either way.
+ *   gsr_last_num_rendered() returns the calling thread's last forward's exact num_rendered (the
+ *   reference's return value) without touching the device.
+ * The host-thread state behind this (mailbox word, counters, prediction) is per thread and device;
+ * one thread's forwards must be ordered on the device (ONE stream at a time per host thread -- the
+ * reference uses the default stream only); a thread that changes streams is detected and the
+ * previous stream is drained first.  Calls from different host threads are independent. */
 int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
                 gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
                 int height, const float* means3D, const float* shs, const float* colors_precomp,
@@ -62,9 +78,18 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
                 float tan_fovx, float tan_fovy, int prefiltered, float* out_color, float* out_depth, float* out_acc,
                 int* radii, int debug, void* stream);
 
+int gsr_last_num_rendered(void);
+/* Test / tuning hook for the speculative forward: capacity >= 1 = the calling thread's NEXT forward
+ * allocates its binning blob for exactly that many instances (smaller than num_rendered forces the
+ * overflow path); 0 = forget the thread's history (its next forward is synchronous); negative = no
+ * override.  Returns the previous override (-1 = none). */
+long long gsr_set_binning_capacity_hint(long long capacity);
+unsigned long long gsr_speculative_forwards(void);  /* process-wide counters */
+unsigned long long gsr_speculation_overflows(void);
+
 /* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:53-88,
  * rasterizer_impl.cu:346-457).  geom/binning/image blobs are the ones the forward
- * allocator callbacks returned; R is gsr_forward's return value.
+ * allocator callbacks returned; R is gsr_forward's return value (the binning key).
  * The nine gradient outputs are FULLY OVERWRITTEN (Gaussians with radii <= 0 get
  * zeros), so the caller need not pre-zero them (the reference requires zeroed buffers,
  * rasterize_points.cu:173-181; zeroed buffers remain valid input).
@@ -107,6 +132,7 @@ typedef struct gsr_geometry_view {
                                      pipeline: filled only when the forward ran with debug != 0) */
   const uint8_t* clamped;         /* [P] bit0..2 = r,g,b clamp flags      */
   const uint32_t* depth_order;    /* [P] Gaussian ids by (depth bits, id); culled Gaussians last */
+  const uint32_t* num_rendered;   /* [1] the forward's instance count (device memory)           */
 } gsr_geometry_view;
 /* The reference's 64-bit sorted key of instance i is ((uint64)tile << 32) | bits(depths[point_list[i]]) with
  * tile = the tile whose range [ranges[tile][0], ranges[tile][1]) contains i: this implementation sorts the
@@ -213,6 +239,8 @@ int gsr_pack_ply_rows(int P, int M, const float* xyz, const float* features_dc, 
 /* Optional per-kernel device timing (hipEvent pairs recorded on the launch stream around every
  * kernel launch while enabled).  Measurement aid for bench.py's roofline line; the reference has only
  * host wall-clock timers (include/common/timer/timer.h:36-52).  Not thread-safe; off by default.
+ *   (the event pool is guarded by a mutex; enabling / reading while other threads launch is safe, the
+ *   attribution of events to forwards of concurrent threads is then simply interleaved)
  *   gsr_profile_enable(1) starts a fresh recording, gsr_profile_enable(0) stops it.
  *   gsr_profile_read synchronises the recorded events, writes per-kernel total milliseconds and launch
  *   counts for kernel ids [0, gsr_kernel_count()), clears the recording, returns the number of ids written. */
@@ -227,6 +255,19 @@ int gsr_profile_read(int max_ids, double* total_ms, int* launches);
  * fallback stream query instead of the polled mailbox word (0 in a healthy run; each one leaves the GPU idle for up
  * to one query period, 25 us). */
 unsigned long long gsr_mailbox_slow_path_hits(void);
+/* ... and what the most recent such exit saw: the ticket it waited for, the ticket in the word at the last spin
+ * and right after the first successful hipStreamQuery, the time since the enqueue, and whether the word was
+ * already there when that HIP call returned (1 = the count was only invisible to the spinning load until a HIP
+ * call was made; 0 = the store itself arrived after the stream had drained).  count = 0: never happened. */
+typedef struct gsr_mailbox_event {
+  unsigned count;
+  uint32_t ticket_expected, ticket_seen_before_query;
+  double elapsed_us;
+  uint32_t ticket_seen_after_query;
+  int first_query_result;
+  int visible_at_query;
+} gsr_mailbox_event;
+int gsr_mailbox_slow_path_last(gsr_mailbox_event* out);
 
 const char* gsr_last_error(void);
 int gsr_abi_version(void);
