@@ -313,7 +313,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const uint2* __restrict__ slotinfo,
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dacc, float4* __restrict__ grad_inst,
-    uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched) {
+    uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_order) {
   constexpr int LW = BCHUNK / 64;  // loader waves
   // one 48-byte image per staged entry -- (x, y, conic.x', conic.y' | conic.z', opacity, r, g | b, conic) with the
   // primed terms pre-scaled for exp2 -- so a visit
@@ -326,17 +326,18 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   // per visit
   __shared__ __attribute__((aligned(16))) float sPart[4][BCHUNK][12];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int tile = blockIdx.y * fp.gx + blockIdx.x;
+  const int tile = tile_order ? (int)tile_order[blockIdx.x] : (int)blockIdx.x;  // longest walk first (k_tile_order)
+  const int tile_x = tile % fp.gx, tile_y = tile / fp.gx;
   const uint32_t ql0 = quad_last_in[4 * tile], ql1 = quad_last_in[4 * tile + 1], ql2 = quad_last_in[4 * tile + 2],
                  ql3 = quad_last_in[4 * tile + 3];
   const int n = (int)max(max(ql0, ql1), max(ql2, ql3));  // entries [0, n) of the tile's list can carry gradient
   if (n == 0) return;
   const uint32_t rbase = ranges[tile].x;
-  const int px = blockIdx.x * TILE + (w & 1) * 8 + (lane & 7);
-  const int py = blockIdx.y * TILE + (w >> 1) * 8 + (lane >> 3);
+  const int px = tile_x * TILE + (w & 1) * 8 + (lane & 7);
+  const int py = tile_y * TILE + (w >> 1) * 8 + (lane >> 3);
   const bool inside = px < fp.W && py < fp.H;
   const float pfx = (float)px, pfy = (float)py;
-  const float tx0 = (float)(blockIdx.x * TILE), ty0 = (float)(blockIdx.y * TILE);
+  const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
   const size_t pid = (size_t)fp.W * py + px, N = (size_t)fp.W * fp.H;
 
   const float T_final = inside ? final_T[pid] : 0.0f;
@@ -373,7 +374,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
       sE[tid][1] = make_float4(b.x * (-0.5f * L2E), b.y, b.z, b.w);
       sE[tid][2] = make_float4(c.x, a.z, a.w, b.x);
       sId[tid] = id;
-      sSlot[tid] = si.x + (uint32_t)(((int)blockIdx.y - y0) * rw + ((int)blockIdx.x - x0));
+      sSlot[tid] = si.x + (uint32_t)((tile_y - y0) * rw + (tile_x - x0));
       hits = quad_hits(a.x, a.y, c.z, c.w, tx0, ty0);
       if (hits && c.z < 1.0e6f) {  // box passed: ask the ellipse itself, quad by quad
         const float tau = footprint_tau(b.y);
@@ -718,27 +719,28 @@ hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                  const float* dL_dpix, const float* dL_dacc, hipStream_t s) {
   ProfScope ps_k_blend_bwd(K_BLEND_BWD, s);
-  // GSR_BLEND_BACKWARD_QUADS=1 (diagnostics / A-B): the wave-per-quad kernel with its LDS combine step
-  static const bool per_quad = getenv("GSR_BLEND_BACKWARD_QUADS") != nullptr;
+  // Two kernels, chosen by the number of tiles.  One wave per tile (four pixels per lane, one reduction per 256
+  // pixels) needs a frame with at least ~3000 tiles to fill the chip -- a tile is one wave's serial job -- and then wins
+  // (1080p: 0.21 vs 0.28 ms; 1280x720: 0.141 vs 0.162); on the small frames of the product (640x512 = 1280 tiles) four
+  // waves per tile keep four times as many waves in flight (0.121 vs 0.327 ms).  Both take the tiles longest walk
+  // first.  GSR_BLEND_BACKWARD_QUADS=1 / GSR_BLEND_BACKWARD_TILES=1 force one of them (diagnostics, tests).
+  static const bool force_quad = getenv("GSR_BLEND_BACKWARD_QUADS") != nullptr;
+  static const bool force_tile = getenv("GSR_BLEND_BACKWARD_TILES") != nullptr;
+  static const bool image_order = getenv("GSR_BWD_IMAGE_ORDER") != nullptr;  // experiment knob
+  const int tiles = fp.gx * fp.gy;
+  const bool per_quad = force_quad || (!force_tile && tiles < 3072);
+  const uint32_t* order = image_order ? nullptr : im.tile_order;
+  if (order) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.quad_last, tiles, im.tile_order);
   if (per_quad) {
     // chunks of 128 list entries (64 and 128 measured equal, 256 slower: LDS footprint)
-    hipLaunchKernelGGL(k_blend_backward<128>, dim3(fp.gx, fp.gy), dim3(256), 0, s, fp, im.ranges, im.quad_last,
-                       b.point_list, g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst,
-                       b.inst_flag, g.touched);
+    hipLaunchKernelGGL(k_blend_backward<128>, dim3(tiles), dim3(256), 0, s, fp, im.ranges, im.quad_last, b.point_list,
+                       g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst, b.inst_flag,
+                       g.touched, order);
   } else {
-    const int tiles = fp.gx * fp.gy;
-    static const int tw = getenv("GSR_BWD_TW") ? atoi(getenv("GSR_BWD_TW")) : 4;  // experiment knob
-    static const bool image_order = getenv("GSR_BWD_IMAGE_ORDER") != nullptr;     // experiment knob
-    const uint32_t* order = image_order ? nullptr : im.tile_order;
-    if (order) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.quad_last, tiles, im.tile_order);
-#define GSR_LAUNCH_BWD_TILE(TW)                                                                                        \
-  hipLaunchKernelGGL(k_blend_backward_tile<TW>, dim3((tiles + TW - 1) / TW), dim3(64 * TW), 0, s, fp, im.ranges,        \
-                     im.quad_last, b.point_list, g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc,  \
-                     reinterpret_cast<float*>(b.grad_inst), b.inst_flag, g.touched, order)
-    if (tw == 1) GSR_LAUNCH_BWD_TILE(1);
-    else if (tw == 2) GSR_LAUNCH_BWD_TILE(2);
-    else GSR_LAUNCH_BWD_TILE(4);
-#undef GSR_LAUNCH_BWD_TILE
+    constexpr int TW = 4;  // (1, 2 and 4 tiles per workgroup measured equal)
+    hipLaunchKernelGGL(k_blend_backward_tile<TW>, dim3((tiles + TW - 1) / TW), dim3(64 * TW), 0, s, fp, im.ranges,
+                       im.quad_last, b.point_list, g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc,
+                       reinterpret_cast<float*>(b.grad_inst), b.inst_flag, g.touched, order);
   }
   return hipGetLastError();
 }

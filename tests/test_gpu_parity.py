@@ -393,6 +393,47 @@ def test_sort_fallback_paths(knob, gpu_device):
     assert out.returncode == 0 and "fallback ok" in out.stdout, out.stderr[-2000:]
 
 
+@pytest.mark.parametrize("knob", ["GSR_BLEND_BACKWARD_TILES", "GSR_BLEND_BACKWARD_QUADS", "GSR_BWD_IMAGE_ORDER",
+                                  "GSR_SYNC_FORWARD"])
+def test_blend_backward_kernel_variants(knob, gpu_device):
+    """The blend backward has two kernels -- one wave per tile (four pixels per lane) for frames of >= 3072 tiles, one
+    wave per 8x8 quad below -- and takes the tiles longest walk first.  The size rule alone would leave the tile
+    kernel untested on the small scenes the oracle can check in full and the quad kernel untested on large frames, so
+    each variant is forced on both (the knobs are read once per process: child process), gradients against the oracle;
+    GSR_SYNC_FORWARD=1 = every forward synchronous."""
+    import subprocess
+    import sys
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import torch, gs_livm_amd as G\n"
+        "from gs_livm_amd import synthetic as S\n"
+        "from oracle import oracle as O\n"
+        "from helpers import hip_forward, hip_backward, grad_close, conic_condition\n"
+        "dev = torch.device('cuda:0')\n"
+        "for (P, W, H, seed, D) in ((300, 70, 50, 11, 3), (6000, 320, 200, 16, 0), (40000, 500, 300, 6, 1), (7, 33, 17, 3, 1),\n"
+        "                           (60000, 1300, 800, 8, 0)):\n"
+        "    sc = S.make_scene(P, W, H, seed, sh_degree=D)\n"
+        "    if P == 6000:\n"
+        "        sc['means3D'][:20, 2] = 1.0; sc['means3D'][:20, :2] *= 0.2; sc['scales'][:20] = 0.29\n"
+        "    O.set_threads(min(O.max_threads(), 16))\n"
+        "    fr = O.forward(sc)\n"
+        "    keep = (fr.fragile == 0).astype(np.float32)[None]\n"
+        "    dcol, dacc = S.make_upstream_grads(W, H, seed)\n"
+        "    dcol, dacc = dcol * keep, dacc * keep\n"
+        "    ref = O.backward(fr, sc, dcol, dacc)\n"
+        "    cond = conic_condition(fr.conic_opacity)  # the conditioning-aware bound of helpers.grad_close\n"
+        "    for rep in range(2):\n"
+        "        t, fwd = hip_forward(sc, dev, debug=False)\n"
+        "        got = hip_backward(sc, t, fwd, dcol, dacc, dev, debug=False)\n"
+        "        for k in ref:\n"
+        "            grad_close(got[k], ref[k], k, cond=cond)\n"
+        "print('variant ok')\n") % (os.path.dirname(GOLDEN.rstrip('/').rsplit('/', 1)[0]), os.path.dirname(GOLDEN))
+    env = dict(os.environ, **{knob: "1"})
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "variant ok" in out.stdout, out.stderr[-2000:]
+
+
 def test_randomised_scenes(gpu_device):
     """Twelve seeded random configurations -- image size, field of view, camera yaw / position, SH degree, Gaussian
     count, anisotropy and opacity ranges, background, scale modifier, non-unit quaternions -- through the full
