@@ -19,7 +19,7 @@ ALLOC_FN = C.CFUNCTYPE(C.c_void_p, C.c_void_p, C.c_size_t)
 class GeometryView(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in
                 ("depths", "radii", "splats", "cov3D", "tiles_touched", "point_offsets", "clamped", "depth_order",
-                 "num_rendered")]
+                 "num_rendered", "gpack")]
 
 
 class BinningView(C.Structure):
@@ -305,11 +305,13 @@ def state_views(geomBuffer, binningBuffer, imageBuffer, P, R, W, H):
     out = {}
     if P:
         _check(L.gsr_geometry_view_of(_ptr(geomBuffer), P, C.byref(gv)))
-        out.update(depths=_sub(geomBuffer, gv.depths, P, torch.float32),
-                   radii=_sub(geomBuffer, gv.radii, P, torch.int32),
-                   splats=_sub(geomBuffer, gv.splats, P * 12, torch.float32).view(P, 12),
-                   cov3D=_sub(geomBuffer, gv.cov3D, P * 6, torch.float32).view(P, 6),
-                   tiles_touched=_sub(geomBuffer, gv.tiles_touched, P, torch.int32),
+        splats = _sub(geomBuffer, gv.splats, P * 12, torch.float32).view(P, 12)
+        gpack = _sub(geomBuffer, gv.gpack, P * 2, torch.int32).view(P, 2)
+        out.update(depths=splats[:, 9],  # (culled Gaussians have no record: compare where radii > 0)
+                   radii=_sub(geomBuffer, gv.radii, P, torch.int32),  # valid only if the forward got no radii array
+                   splats=splats,
+                   cov3D=_sub(geomBuffer, gv.cov3D, P * 6, torch.float32).view(P, 6),  # debug forwards only
+                   tiles_touched=gpack[:, 0],
                    point_offsets=_sub(geomBuffer, gv.point_offsets, P, torch.int32),
                    clamped=_sub(geomBuffer, gv.clamped, P, torch.uint8),
                    depth_order=_sub(geomBuffer, gv.depth_order, P, torch.int32))

@@ -312,7 +312,7 @@ static int enqueue_binning_and_blend(const FrameParams& fp, GeomState& g, ImageS
   else
     STAGE(launch_tile_ranges(b.tkeysA, cnt, im.ranges, key16, stream));
   if (debug) {  // self-check of the binning chain: every list ordered by (depth bits, id)
-    HIP_TRY(launch_verify_sorted_lists(im.ranges, tiles, b.point_list, g.depths, g.total + 4, stream));
+    HIP_TRY(launch_verify_sorted_lists(im.ranges, tiles, b.point_list, g.splats, g.total + 4, stream));
     uint32_t bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, g.total + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
@@ -391,8 +391,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   uint32_t* const ghist_acc = own_hist_pass ? nullptr : ghist2 + 1024 * c.hist_flip;
   uint32_t* const ghist_clear = own_hist_pass ? nullptr : ghist2 + 1024 * (c.hist_flip ^ 1u);
   STAGE(launch_preprocess(fp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
-                          projmatrix, cam_pos, g, radii, c.done_counter, c.mailbox_dev, c.ticket, ghist_acc, ghist_clear,
-                          stream));
+                          projmatrix, cam_pos, g, radii, /*write_cov3D=*/debug != 0, c.done_counter, c.mailbox_dev, c.ticket,
+                          ghist_acc, ghist_clear, stream));
   STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, ghist_acc, stream));
   if (debug) STAGE(launch_point_offsets(fp, g, stream));  // the reference's array, for the views only
 
@@ -506,7 +506,6 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
   BinningState b = BinningState::carve(binning_buffer, (size_t)R);
   ImageState im = ImageState::carve(image_buffer, width, height);
   if (!radii) radii = g.radii;  // rasterizer_impl.cu:386-388
-  const float* cov3D_used = cov3D_precomp ? cov3D_precomp : g.cov3D;  // rasterizer_impl.cu:427
 
   if (R > 0) {
     // inst_flag, touched and total[2] are zero here: the forward initialises them and the gather kernels
@@ -515,7 +514,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
     STAGE(launch_gather_records(fp, g, b, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, stream));
   }
   STAGE(launch_gaussian_backward(fp, g, b, radii, means3D, scales, rotations, colors_precomp ? nullptr : shs,
-                                 cov3D_used, viewmatrix, projmatrix, campos, colors_precomp != nullptr, dL_dmean2D,
+                                 cov3D_precomp, viewmatrix, projmatrix, campos, colors_precomp != nullptr, dL_dmean2D,
                                  dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
                                  stream));
   return GSR_OK;
@@ -648,11 +647,12 @@ int gsr_pack_ply_rows(int P, int M, const float* xyz, const float* features_dc, 
 int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out) {
   if (!geom_buffer || !out || P < 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad argument");
   GeomState g = GeomState::carve(geom_buffer, (size_t)P);
-  out->depths = g.depths;
+  out->depths = nullptr;  // not kept: the view-space depth is splats[i][9]
   out->radii = g.radii;
   out->splats = reinterpret_cast<const float*>(g.splats);
   out->cov3D = g.cov3D;
-  out->tiles_touched = g.tiles_touched;
+  out->tiles_touched = nullptr;  // not kept separately: gpack[i][0]
+  out->gpack = reinterpret_cast<const uint32_t*>(g.gpack);
   out->point_offsets = g.point_offsets;
   out->clamped = g.clamped;
   out->depth_order = g.order;

@@ -95,17 +95,16 @@ struct DepthSortScratch {
 };
 
 struct GeomState {
-  float* depths;
-  int32_t* radii;
-  float4* splats;
-  float* cov3D;
-  uint32_t* tiles_touched;
-  uint32_t* point_offsets;  // inclusive scan of tiles_touched in Gaussian-id order (= the reference's array);
+  int32_t* radii;           // internal radii: written only when the caller passes no radii array of its own
+  float4* splats;           // (view-space depth = splats[3 i + 2].y: no separate depth array)
+  float* cov3D;             // debug forwards only (views); the backward recomputes it from scale and rotation
+  uint32_t* point_offsets;  // inclusive scan of the tile counts in Gaussian-id order (= the reference's array);
                             // not used by this pipeline: filled only by a debug forward (for the views)
   uint8_t* clamped;         // bit0..2
   uint32_t* total;          // [1] num_rendered, device side
   uint2* slotinfo;          // {first slot of the Gaussian's instance run, x0 | y0 << 10 | rect_width << 20}
-  uint2* gpack;             // {tiles_touched, packed rect} per Gaussian: ONE 8-byte gather in depth order
+  uint2* gpack;             // {tiles_touched, packed rect} per Gaussian: ONE 8-byte gather in depth order (the only
+                            // copy of the tile counts)
   uint32_t* order;          // [P] Gaussian ids sorted by (depth bits, id); culled Gaussians last.  = dvalsA
   uint32_t* dkeysA;         // [P] depth-sort ping-pong buffers
   uint32_t* dkeysB;
@@ -120,11 +119,9 @@ struct GeomState {
   static GeomState carve(char* blob, size_t P, size_t* bytes = nullptr) {
     Carver c(blob);
     GeomState g;
-    g.depths = c.take<float>(P);
     g.radii = c.take<int32_t>(P);
     g.splats = c.take<float4>(P * SPLAT_F4);
     g.cov3D = c.take<float>(P * 6);
-    g.tiles_touched = c.take<uint32_t>(P);
     g.point_offsets = c.take<uint32_t>(P);
     g.clamped = c.take<uint8_t>(P);
     g.total = c.take<uint32_t>(64);
@@ -228,7 +225,7 @@ bool preprocess_counts_depth_digits(const FrameParams& fp, const float* shs, con
 hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const float* scales, const float* rotations,
                              const float* opacities, const float* shs, const float* cov3D_precomp,
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,
-                             GeomState g, int* radii_out, unsigned long long* done_word,
+                             GeomState g, int* radii_out, bool write_cov3D, unsigned long long* done_word,
                              unsigned long long* publish, uint32_t ticket, uint32_t* ghist_acc, uint32_t* ghist_clear,
                              hipStream_t s);
 hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
@@ -258,7 +255,7 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
                              int n, const uint32_t* ghist, hipStream_t s);
 hipError_t launch_ranges_from_counts(uint2* ranges, int T, hipStream_t s);
-hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t* point_list, const float* depths,
+hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t* point_list, const float4* splats,
                                       uint32_t* violations, hipStream_t s);
 hipError_t launch_tile_ranges(const uint32_t* tile_ids, Count R, uint2* ranges, bool key16, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
@@ -267,7 +264,7 @@ hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningStat
                                  const float* dL_dpix, const float* dL_dacc, hipStream_t s);
 hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningState b, const int* radii,
                                     const float* means3D, const float* scales, const float* rotations,
-                                    const float* shs, const float* cov3D_used, const float* view, const float* proj,
+                                    const float* shs, const float* cov3D_precomp, const float* view, const float* proj,
                                     const float* campos, bool colors_precomp, float* dL_dmean2D, float* dL_dconic,
                                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                                     float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s);

@@ -17,6 +17,8 @@
 // evaluation order of the reference (GLM column-major products, accumulated left to right) so the
 // rounding matches the unfused CPU oracle bit for bit.  Divisions and sqrt are IEEE (hipcc default
 // -fhip-fp32-correctly-rounded-divide-sqrt).
+#include <cstdlib>
+
 #include "gsr_internal.hpp"
 #include "sort_core.hpp"
 
@@ -190,7 +192,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
     const float* __restrict__ cov3D_precomp, const float* __restrict__ colors_precomp,
     const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos, GeomState g,
-    int* __restrict__ radii_out, unsigned long long* __restrict__ done_word,
+    int* __restrict__ radii_out, const bool write_cov3D, unsigned long long* __restrict__ done_word,
     unsigned long long* __restrict__ publish,
     const uint32_t ticket, uint32_t* __restrict__ ghist_acc, uint32_t* __restrict__ ghist_clear) {
   // Persistent-style grid: the launcher sizes the grid to ONE resident round of workgroups (preprocess_grid) and
@@ -271,8 +273,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
         for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * idx + k];
       } else {
         cov3d_from_scale_rot(s0, s1, s2, in.q, c6);
+        if (write_cov3D) {  // debug forwards only (the views): the backward recomputes it with the same arithmetic
 #pragma unroll
-        for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)idx + k] = c6[k];
+          for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)idx + k] = c6[k];
+        }
       }
       const Ewa e = ewa_project(mx, my, mz, fp, c6, V);
       const float cx = e.cxx + 0.3f, cy = e.cxy, cz = e.cyy + 0.3f;
@@ -296,9 +300,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
             rgb[1] = colors_precomp[3 * idx + 1];
             rgb[2] = colors_precomp[3 * idx + 2];
           } else {  // SH -> RGB (forward.cu:29-76)
-            const float d0 = mx - campos[0], d1 = my - campos[1], d2 = mz - campos[2];
-            const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
-            const float x = d0 / len, y = d1 / len, z = d2 / len;
+            float x = 0.f, y = 0.f, z = 0.f;
+            if (fp.D > 0) {  // the view direction only enters from degree 1 on (the product runs degree 0)
+              const float d0 = mx - campos[0], d1 = my - campos[1], d2 = mz - campos[2];
+              const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
+              x = d0 / len; y = d1 / len; z = d2 / len;
+            }
             const float* sh = STAGED ? sh_rows + threadIdx.x * sh_row_stride(fp.M * 3) : shs + (size_t)idx * fp.M * 3;
             const float dc[3] = {dc_direct ? in.dc0 : sh[0], dc_direct ? in.dc1 : sh[1], dc_direct ? in.dc2 : sh[2]};
 #pragma unroll
@@ -366,7 +373,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
           tiles = (x1 > x0 && y1 > y0) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
           rect_packed = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
           if (tiles) dkey = __float_as_uint(pvz);  // depth > 0.2: the bit pattern orders like the value
-          g.depths[idx] = pvz;
           float4* rec = g.splats + (size_t)idx * SPLAT_F4;
           rec[0] = make_float4(pixx, pixy, conx, cony);
           rec[1] = make_float4(conz, op, rgb[0], rgb[1]);
@@ -375,9 +381,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
         }
       }
     }
-    g.radii[idx] = radius;
-    if (radii_out) radii_out[idx] = radius;
-    g.tiles_touched[idx] = tiles;
+    radii_out[idx] = radius;  // the caller's array, or the blob's own when it passed none (launcher)
     g.gpack[idx] = make_uint2(tiles, tiles ? rect_packed : 0u);
     g.touched[idx] = 0;  // backward bookkeeping starts clean (the backward clears what it sets)
     if (idx == 0) g.total[2] = 0u;
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
 // reads it (slots are assigned in depth order by k_scan_offsets), so this is one workgroup walking
 // the array: simple, and off the production path.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(1024) void k_point_offsets(const int P, const uint32_t* __restrict__ tiles_touched,
+__global__ __launch_bounds__(1024) void k_point_offsets(const int P, const uint2* __restrict__ gpack,
                                                         uint32_t* __restrict__ point_offsets) {
   __shared__ uint32_t wtot[16];
   __shared__ uint32_t carry_s;
@@ -451,7 +455,7 @@ __global__ __launch_bounds__(1024) void k_point_offsets(const int P, const uint3
   __syncthreads();
   for (int base = 0; base < P; base += 1024) {
     const int i = base + tid;
-    const uint32_t v = i < P ? tiles_touched[i] : 0u;
+    const uint32_t v = i < P ? gpack[i].x : 0u;
     const uint32_t inc = wave_incl_scan_u32(v, lane);
     if (lane == 63) wtot[w] = inc;
     __syncthreads();
@@ -843,7 +847,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
   for (uint32_t q = wid; q < count; q += nwaves) {
     const uint32_t id = g.tlist[q];
     const size_t first = g.slotinfo[id].x;
-    const uint32_t n = g.tiles_touched[id];
+    const uint32_t n = g.gpack[id].x;
     float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0;
     for (uint32_t base = 0; base < n; base += 256) {
       uint8_t f[4];
@@ -908,7 +912,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
 __device__ __forceinline__ void gaussian_backward_one(
     const int idx, float* row,
     const FrameParams& fp, GeomState& g, const int* __restrict__ radii, const float* __restrict__ means3D, const float* __restrict__ scales,
-    const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ cov3D_used,
+    const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos,
     const int colors_are_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
     float* __restrict__ dL_dmean3D,
@@ -924,15 +928,22 @@ __device__ __forceinline__ void gaussian_backward_one(
   const float i_ca = dL_dconic[4 * idx], i_cb = dL_dconic[4 * idx + 1], i_cc = dL_dconic[4 * idx + 3];
   const float i_op = dL_dopacity[idx];
   const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
-  float c6[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) c6[k] = cov3D_used[6 * (size_t)idx + k];
   const uint8_t clamped_in = g.clamped[idx];
   float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
   float sc_in[3] = {0.f, 0.f, 0.f};
   if (scales) {
     q_in = reinterpret_cast<const float4*>(rotations)[idx];
     sc_in[0] = scales[3 * idx]; sc_in[1] = scales[3 * idx + 1]; sc_in[2] = scales[3 * idx + 2];
+  }
+  // The 3D covariance is not kept by the forward (24 B written + 24 B read per Gaussian): it is recomputed here with
+  // the forward's own arithmetic (same function, same unfused file), so it is the same bits (rasterizer_impl.cu:427
+  // reads geomState.cov3D instead).
+  float c6[6];
+  if (cov3D_precomp) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * (size_t)idx + k];
+  } else {
+    cov3d_from_scale_rot(fp.scale_modifier * sc_in[0], fp.scale_modifier * sc_in[1], fp.scale_modifier * sc_in[2], q_in, c6);
   }
   const bool vis = rad_in > 0;
   const float* sh = row ? row : shs + (size_t)idx * fp.M * 3;
@@ -1139,7 +1150,7 @@ __device__ __forceinline__ void gaussian_backward_one(
 template <bool STAGED>
 __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
     const FrameParams fp, GeomState g, const int* __restrict__ radii, const float* __restrict__ means3D, const float* __restrict__ scales,
-    const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ cov3D_used,
+    const float* __restrict__ rotations, const float* __restrict__ shs, const float* __restrict__ cov3D_precomp,
     const float* __restrict__ V, const float* __restrict__ Pm, const float* __restrict__ campos,
     const int colors_are_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
     float* __restrict__ dL_dmean3D,
@@ -1154,7 +1165,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
   }
   if (idx < fp.P)
     gaussian_backward_one(idx, STAGED ? sh_rows + threadIdx.x * sh_row_stride(C) : nullptr, fp, g, radii, means3D, scales,
-                          rotations, shs, cov3D_used, V, Pm, campos, colors_are_precomp, dL_dmean2D, dL_dconic,
+                          rotations, shs, cov3D_precomp, V, Pm, campos, colors_are_precomp, dL_dmean2D, dL_dconic,
                           dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
   if (STAGED) {
     __syncthreads();
@@ -1185,23 +1196,25 @@ bool preprocess_counts_depth_digits(const FrameParams& fp, const float* shs, con
 hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const float* scales, const float* rotations,
                              const float* opacities, const float* shs, const float* cov3D_precomp,
                              const float* colors_precomp, const float* view, const float* proj, const float* campos,
-                             GeomState g, int* radii_out, unsigned long long* done_word,
+                             GeomState g, int* radii_out, bool write_cov3D, unsigned long long* done_word,
                              unsigned long long* publish, uint32_t ticket, uint32_t* ghist_acc, uint32_t* ghist_clear,
                              hipStream_t s) {
+  if (!radii_out) radii_out = g.radii;  // rasterizer_impl.cu:217-219
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps_k_preprocess(K_PREPROCESS, s);
   const size_t stage = (shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0;  // M > 1: SH rows go through LDS
   // one resident round: 8 workgroups of 4 waves per CU (3 when 50 KB of LDS each hold SH rows) x 256 CUs, the
   // blocks spread evenly over them (C3 measured: 6 per CU 101 us, 8 per CU 80 us, 16 per CU 93 us)
-  const int max_wg = (stage ? 3 : 8) * 256, rounds = (nb + max_wg - 1) / max_wg;
+  static const int wg_per_cu = getenv("GSR_PRE_WG_PER_CU") ? atoi(getenv("GSR_PRE_WG_PER_CU")) : 8;  // experiment knob
+  const int max_wg = (stage ? 3 : wg_per_cu) * 256, rounds = (nb + max_wg - 1) / max_wg;
   const dim3 grid(rounds ? (nb + rounds - 1) / rounds : 1);
   if (stage)
     hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(PRE_BLOCK), stage, s, fp, means3D, scales, rotations, opacities,
-                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket,
+                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, write_cov3D, done_word, publish, ticket,
                        ghist_acc, ghist_clear);
   else
     hipLaunchKernelGGL(k_preprocess<false>, grid, dim3(PRE_BLOCK), 0, s, fp, means3D, scales, rotations, opacities,
-                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, done_word, publish, ticket,
+                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, write_cov3D, done_word, publish, ticket,
                        ghist_acc, ghist_clear);
   return hipGetLastError();
 }
@@ -1209,7 +1222,7 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
 // debug forwards only: the reference's point_offsets array for the views
 hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t s) {
   ProfScope ps(K_POINT_OFFSETS, s);
-  hipLaunchKernelGGL(k_point_offsets, dim3(1), dim3(1024), 0, s, fp.P, g.tiles_touched, g.point_offsets);
+  hipLaunchKernelGGL(k_point_offsets, dim3(1), dim3(1024), 0, s, fp.P, g.gpack, g.point_offsets);
   return hipGetLastError();
 }
 
@@ -1276,7 +1289,7 @@ hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningStat
 
 hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningState b, const int* radii,
                                     const float* means3D, const float* scales, const float* rotations,
-                                    const float* shs, const float* cov3D_used, const float* view, const float* proj,
+                                    const float* shs, const float* cov3D_precomp, const float* view, const float* proj,
                                     const float* campos, bool colors_precomp, float* dL_dmean2D, float* dL_dconic,
                                     float* dL_dopacity, float* dL_dcolor, float* dL_dmean3D, float* dL_dcov3D,
                                     float* dL_dsh, float* dL_dscale, float* dL_drot, hipStream_t s) {
@@ -1285,11 +1298,11 @@ hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningS
   const size_t stage = (shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0;  // M > 1: SH / dL_dsh rows go through LDS
   if (stage)
     hipLaunchKernelGGL(k_gaussian_backward<true>, dim3(nb), dim3(PRE_BLOCK), stage, s, fp, g, radii,
-                       means3D, scales, rotations, shs, cov3D_used, view, proj, campos, 0,
+                       means3D, scales, rotations, shs, cov3D_precomp, view, proj, campos, 0,
                        dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
   else
     hipLaunchKernelGGL(k_gaussian_backward<false>, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, radii,
-                       means3D, scales, rotations, shs, cov3D_used, view, proj, campos, colors_precomp ? 1 : 0,
+                       means3D, scales, rotations, shs, cov3D_precomp, view, proj, campos, colors_precomp ? 1 : 0,
                        dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
   return hipGetLastError();
 }

@@ -194,7 +194,7 @@ static bool lds_atomic_rank_ok(hipStream_t s) {
 // in particular of the returning-LDS-atomic ranking whose lane order the ISA manual does not document.
 __global__ __launch_bounds__(256) void k_verify_sorted_lists(const uint2* __restrict__ ranges, const int T,
                                                              const uint32_t* __restrict__ point_list,
-                                                             const float* __restrict__ depths,
+                                                             const float4* __restrict__ splats,
                                                              uint32_t* __restrict__ violations) {
   const int tile = blockIdx.x;
   if (tile >= T) return;
@@ -202,17 +202,17 @@ __global__ __launch_bounds__(256) void k_verify_sorted_lists(const uint2* __rest
   uint32_t bad = 0;
   for (uint32_t i = r.x + 1 + threadIdx.x; i < r.y; i += 256) {
     const uint32_t a = point_list[i - 1], b = point_list[i];
-    const uint32_t da = __float_as_uint(depths[a]), db = __float_as_uint(depths[b]);
+    const uint32_t da = __float_as_uint(splats[(size_t)a * SPLAT_F4 + 2].y), db = __float_as_uint(splats[(size_t)b * SPLAT_F4 + 2].y);
     if (da > db || (da == db && a >= b)) bad++;
   }
   if (bad) atomicAdd(violations, bad);
 }
 
-hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t* point_list, const float* depths,
+hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t* point_list, const float4* splats,
                                       uint32_t* violations, hipStream_t s) {
   hipError_t e = hipMemsetAsync(violations, 0, sizeof(uint32_t), s);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_verify_sorted_lists, dim3(T), dim3(256), 0, s, ranges, T, point_list, depths, violations);
+  hipLaunchKernelGGL(k_verify_sorted_lists, dim3(T), dim3(256), 0, s, ranges, T, point_list, splats, violations);
   return hipGetLastError();
 }
 

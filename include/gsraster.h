@@ -123,16 +123,18 @@ size_t gsr_binning_bytes(int R);
  * Pointers are device pointers into the blob; arrays the implementation does not keep
  * are NULL. */
 typedef struct gsr_geometry_view {
-  const float* depths;            /* [P]                                  */
-  const int32_t* radii;           /* [P] internal radii                   */
+  const float* depths;            /* NULL: not kept (the view-space depth is splats[i][9])              */
+  const int32_t* radii;           /* [P] internal radii: valid only when gsr_forward got radii == NULL  */
   const float* splats;            /* [P][12]: x, y, conic.x, conic.y, conic.z, opacity, r, g, b, depth, hx, hy */
-  const float* cov3D;             /* [P][6]                               */
-  const uint32_t* tiles_touched;  /* [P]                                  */
+  const float* cov3D;             /* [P][6] filled only when the forward ran with debug != 0 (the backward
+                                     recomputes the covariance from scale and rotation)                 */
+  const uint32_t* tiles_touched;  /* NULL: not kept separately (gpack[i][0])                            */
   const uint32_t* point_offsets;  /* [P] inclusive scan in id order (the reference's array; unused by this
                                      pipeline: filled only when the forward ran with debug != 0) */
   const uint8_t* clamped;         /* [P] bit0..2 = r,g,b clamp flags      */
   const uint32_t* depth_order;    /* [P] Gaussian ids by (depth bits, id); culled Gaussians last */
   const uint32_t* num_rendered;   /* [1] the forward's instance count (device memory)           */
+  const uint32_t* gpack;          /* [P][2]: tiles touched, packed tile rect x0 | y0 << 10 | width << 20 */
 } gsr_geometry_view;
 /* The reference's 64-bit sorted key of instance i is ((uint64)tile << 32) | bits(depths[point_list[i]]) with
  * tile = the tile whose range [ranges[tile][0], ranges[tile][1]) contains i: this implementation sorts the

@@ -44,7 +44,7 @@ GRAD_NAMES = ("dL_dmeans2D", "dL_dconic", "dL_dopacity", "dL_dcolors", "dL_dmean
 
 
 def _u32(t):
-    return t.cpu().numpy().view(np.uint32)
+    return np.ascontiguousarray(t.cpu().numpy()).view(np.uint32)
 
 
 def check_forward(sc, fr, fwd, dev, debug=True, max_fragile=5e-3):
@@ -53,8 +53,8 @@ def check_forward(sc, fr, fwd, dev, debug=True, max_fragile=5e-3):
     P, W, H = sc["means3D"].shape[0], sc["W"], sc["H"]
     assert R == fr.R
     v = G.state_views(geom, binning, img, P, R, W, H)
+    assert v["num_rendered"] == fr.R
     assert np.array_equal(radii.cpu().numpy(), fr.radii)
-    assert np.array_equal(v["radii"].cpu().numpy(), fr.radii)
     assert np.array_equal(_u32(v["tiles_touched"]), fr.tiles_touched)
     if debug:  # the reference's id-order scan is not used by the product; only a debug forward fills the view
         assert np.array_equal(_u32(v["point_offsets"]), fr.point_offsets)
@@ -70,7 +70,7 @@ def check_forward(sc, fr, fwd, dev, debug=True, max_fragile=5e-3):
         cl = v["clamped"].cpu().numpy()
         bits = np.stack([(cl >> k) & 1 for k in range(3)], 1)
         assert np.array_equal(bits[vis], fr.clamped[vis])
-    if sc.get("cov3D_precomp") is None:
+    if sc.get("cov3D_precomp") is None and debug:  # kept by debug forwards only (the backward recomputes it)
         assert np.array_equal(v["cov3D"].cpu().numpy()[vis], fr.cov3D[vis])
     if R:
         assert np.array_equal(v["keys"].cpu().numpy().view(np.uint64), fr.keys)
@@ -242,6 +242,28 @@ def test_speculative_forward_equals_the_synchronous_one(gpu_device):
     assert int(fn[0]) == 0 and torch.equal(fn[1], torch.ones_like(fn[1]))
     t4, f4 = hip_forward(sc, dev, debug=False)
     _same_frame(ref, f4, P, W, H)
+
+
+def test_internal_radii_when_the_caller_passes_none(gpu_device):
+    """rasterizer_impl.cu:217-219, 386-388: radii == nullptr -> the geometry state's own array is filled and the
+    backward uses it."""
+    sc = S.make_scene(3000, 160, 96, 21, sh_degree=1)
+    fr = O.forward(sc, tight=True)
+    t = to_dev(sc, gpu_device)
+    fwd = G.rasterize_forward(t["bg"], t["means3D"], t["colors_precomp"], t["opacities"], t["scales"], t["rotations"], 1.0,
+                              t["cov3D_precomp"], t["viewmatrix"], t["projmatrix"], sc["tanfovx"], sc["tanfovy"], 96, 160,
+                              t["shs"], 1, t["campos"], False, True, radii_out=False)
+    v = G.state_views(fwd[5], fwd[6], fwd[7], 3000, fwd[0], 160, 96)
+    assert np.array_equal(v["radii"].cpu().numpy(), fr.radii)
+    dcol, dacc = masked_grads(160, 96, 21, fr.fragile)
+    O.set_threads(1)
+    ref = O.backward(fr, sc, dcol, dacc)
+    g = G.rasterize_backward(t["bg"], t["means3D"], None, t["colors_precomp"], t["scales"], t["rotations"], 1.0,
+                             t["cov3D_precomp"], t["viewmatrix"], t["projmatrix"], sc["tanfovx"], sc["tanfovy"],
+                             torch.from_numpy(dcol).to(gpu_device), torch.from_numpy(dacc).to(gpu_device), t["shs"], 1,
+                             t["campos"], fwd[5], fwd[0], fwd[6], fwd[7], True)
+    grad_close(g[3].cpu().numpy(), ref["dL_dmeans3D"], "dL_dmeans3D")
+    grad_close(g[6].cpu().numpy(), ref["dL_dscales"], "dL_dscales")
 
 
 def test_empty_input_is_a_noop(gpu_device):
