@@ -27,7 +27,7 @@ class BinningView(C.Structure):
 
 
 class ImageView(C.Structure):
-    _fields_ = [(n, C.c_void_p) for n in ("ranges", "final_T", "n_contrib", "quad_last")]
+    _fields_ = [(n, C.c_void_p) for n in ("ranges", "final_T", "n_contrib", "quad_last", "ranges_far")]
 
 
 class MailboxEvent(C.Structure):
@@ -60,7 +60,8 @@ EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_byte
            "gsr_photometric_loss", "gsr_photometric_loss_workspace", "gsr_init_gaussians", "gsr_ply_row_floats",
            "gsr_pack_ply_rows", "gsr_model_step", "gsr_set_reference_rects", "gsr_reference_rects",
            "gsr_last_num_rendered", "gsr_set_binning_capacity_hint", "gsr_speculative_forwards",
-           "gsr_speculation_overflows", "gsr_mailbox_slow_path_last")
+           "gsr_speculation_overflows", "gsr_mailbox_slow_path_last", "gsr_set_near_far", "gsr_near_far",
+           "gsr_last_near_far", "gsr_set_near_far_hints", "gsr_near_far_forwards")
 
 
 def lib():
@@ -110,6 +111,16 @@ def lib():
     for n in ("gsr_speculative_forwards", "gsr_speculation_overflows"):
         getattr(L, n).restype = C.c_ulonglong
         getattr(L, n).argtypes = []
+    L.gsr_set_near_far.restype = ci
+    L.gsr_set_near_far.argtypes = [ci]
+    L.gsr_near_far.restype = ci
+    L.gsr_near_far.argtypes = []
+    L.gsr_last_near_far.restype = ci
+    L.gsr_last_near_far.argtypes = [C.POINTER(C.c_uint), C.POINTER(C.c_uint)]
+    L.gsr_set_near_far_hints.restype = None
+    L.gsr_set_near_far_hints.argtypes = [C.c_longlong, C.c_longlong]
+    L.gsr_near_far_forwards.restype = C.c_ulonglong
+    L.gsr_near_far_forwards.argtypes = []
     L.gsr_mailbox_slow_path_last.restype = ci
     L.gsr_mailbox_slow_path_last.argtypes = [C.POINTER(MailboxEvent)]
     L.gsr_mailbox_slow_path_hits.restype = C.c_ulonglong
@@ -259,6 +270,7 @@ def set_binning_capacity_hint(capacity):
 def speculation_stats():
     L = lib()
     return dict(speculative_forwards=int(L.gsr_speculative_forwards()), overflows=int(L.gsr_speculation_overflows()),
+                near_far_forwards=int(L.gsr_near_far_forwards()),
                 mailbox_slow_path_hits=int(L.gsr_mailbox_slow_path_hits()))
 
 
@@ -266,6 +278,26 @@ def mailbox_slow_path_last():
     ev = MailboxEvent()
     _check(lib().gsr_mailbox_slow_path_last(C.byref(ev)))
     return {n: getattr(ev, n) for n, _ in MailboxEvent._fields_}
+
+
+def set_near_far(on):
+    """Near/far frames (include/gsraster.h): speculative forwards of dense scenes bin the nearest Gaussians first and
+    the rest only where a tile is still unfinished.  Returns the previous setting."""
+    return bool(lib().gsr_set_near_far(int(bool(on))))
+
+
+def set_near_far_hints(near_entries_per_tile=None, far_capacity=None):
+    """Test / tuning hook: near budget in list entries per tile and the far capacity of the calling thread's next
+    near/far forward (None = default / from history)."""
+    lib().gsr_set_near_far_hints(-1 if near_entries_per_tile is None else int(near_entries_per_tile),
+                                 -1 if far_capacity is None else int(far_capacity))
+
+
+def last_near_far():
+    """(was the calling thread's last forward binned near/far, near instances, far instances)"""
+    a, b = C.c_uint(0), C.c_uint(0)
+    split = bool(lib().gsr_last_near_far(C.byref(a), C.byref(b)))
+    return split, int(a.value), int(b.value)
 
 
 def set_reference_rects(on):
@@ -320,16 +352,31 @@ def state_views(geomBuffer, binningBuffer, imageBuffer, P, R, W, H):
                    final_T=_sub(imageBuffer, iv.final_T, W * H, torch.float32).view(H, W),
                    n_contrib=_sub(imageBuffer, iv.n_contrib, W * H, torch.int32).view(H, W),
                    quad_last=_sub(imageBuffer, iv.quad_last, T * 4, torch.int32).view(T, 4))
-        exact = int(_sub(geomBuffer, gv.num_rendered, 1, torch.int32)[0])  # the forward's count, from device memory
-        out["num_rendered"] = exact
-        key, R = _key(R), exact
-        if R:
+        counters = _sub(geomBuffer, gv.num_rendered, 16, torch.int32).cpu().tolist()  # the forward's device counters
+        split = counters[12] == 1
+        exact = counters[6] + counters[8] if split else counters[0]
+        out.update(num_rendered=exact, near_far=split, counters=counters)
+        key = _key(R)
+        if exact:
             _check(L.gsr_binning_view_of(_ptr(binningBuffer), key, C.byref(bv)))
-            # tile of instance i = the tile whose range contains i (the last sort pass marks ranges instead of
-            # storing the sorted tile ids)
-            rg = out["ranges"].long()
-            tile_ids = torch.repeat_interleave(torch.arange(T, device=rg.device), rg[:, 1] - rg[:, 0])
-            point_list = _sub(binningBuffer, bv.point_list, R, torch.int32)
+            raw = _sub(binningBuffer, bv.point_list, key, torch.int32)
+            # A tile's list = its near segment followed by its far segment (near/far frames; the far ranges are (0, 0)
+            # otherwise).  The views present it as the reference does: ONE list per tile, lists back to back in tile
+            # order, `ranges` indexing into `point_list`.
+            ra = out["ranges"].long()
+            rb = _sub(imageBuffer, iv.ranges_far, T * 2, torch.int32).view(T, 2).long()
+            seg_start = torch.stack([ra[:, 0], rb[:, 0]], 1).reshape(-1)
+            seg_len = torch.stack([ra[:, 1] - ra[:, 0], rb[:, 1] - rb[:, 0]], 1).reshape(-1)
+            total = int(seg_len.sum())
+            excl = torch.cumsum(seg_len, 0) - seg_len
+            idx = torch.repeat_interleave(seg_start - excl, seg_len) + torch.arange(total, device=ra.device)
+            point_list = raw[idx]
+            ln = seg_len.view(T, 2).sum(1)
+            ends = torch.cumsum(ln, 0)
+            ranges = torch.stack([ends - ln, ends], 1)
+            ranges[ln == 0] = 0  # the reference's memset leaves (0, 0) for tiles without instances
+            out.update(ranges_near=out["ranges"], ranges_far=rb.int(), ranges=ranges.int())
+            tile_ids = torch.repeat_interleave(torch.arange(T, device=ra.device), ln)
             # the reference's 64-bit sorted keys, recomposed: (tile << 32) | bits(depth of the instance's Gaussian)
             dbits = out["depths"].view(torch.int32)[point_list.long()].long() & 0xFFFFFFFF
             out.update(tile_ids=tile_ids, point_list=point_list, keys=(tile_ids.long() << 32) | dbits)

@@ -200,6 +200,13 @@ struct ThreadCtx {
   int recent_pos = 0;
   long long hint_override = -1;               // gsr_set_binning_capacity_hint
   uint32_t last_R = 0;
+  uint32_t recent_far[4] = {0, 0, 0, 0};      // far-phase instance counts of this thread's recent near/far frames
+  int recent_far_pos = 0;
+  bool have_far = false;
+  long long far_hint_override = -1;           // gsr_set_near_far_hints
+  long long near_entries_override = -1;
+  uint32_t last_near = 0, last_far = 0;
+  bool last_was_near_far = false;
 };
 static thread_local ThreadCtx g_ctx;
 
@@ -221,7 +228,7 @@ static int ctx_prepare(ThreadCtx& c, hipStream_t stream) {
     c.ticket = 0;
     c.hist_flip = 0;
     c.used = false;
-    *c.mailbox = 0;
+    for (int k = 0; k < 8; k++) c.mailbox[k] = 0;  // word 0: num_rendered; near/far frames: 1 = far count, 2 = near count
     (void)hipDeviceSynchronize();  // the counter is zero before any stream uses it
   }
   if (c.used && stream != c.last_stream) {
@@ -238,24 +245,24 @@ static int ctx_prepare(ThreadCtx& c, hipStream_t stream) {
 // completion interrupt, whose wake-up latency was measured at up to 30 ms on virtualised hosts).  Safety net: stream
 // queries from 60 us on, every 25 us -- seen on this pool (2 of ~60 bench processes): the word does not become visible
 // to the spinning load until a HIP call is made; every such exit is counted and described (gsr_mailbox_slow_path_*).
-static int wait_num_rendered(ThreadCtx& c, hipStream_t stream, uint32_t* R_out) {
+static int wait_num_rendered(ThreadCtx& c, hipStream_t stream, uint32_t* R_out, int word = 0) {
   using clk = std::chrono::steady_clock;
   const clk::time_point t0 = clk::now();
   const auto query_period = std::chrono::microseconds(25);
   clk::time_point next_query = t0 + std::chrono::microseconds(60);
   for (;;) {
-    const unsigned long long v = __atomic_load_n(c.mailbox, __ATOMIC_ACQUIRE);
+    const unsigned long long v = __atomic_load_n(c.mailbox + word, __ATOMIC_ACQUIRE);
     if ((uint32_t)(v >> 32) == c.ticket) { *R_out = (uint32_t)v; return GSR_OK; }
     __builtin_ia32_pause();
     if (clk::now() < next_query) continue;
     // slow path: notice a faulted or drained stream instead of spinning for ever
     const hipError_t q = hipStreamQuery(stream);
-    const unsigned long long v1 = __atomic_load_n(c.mailbox, __ATOMIC_ACQUIRE);
+    const unsigned long long v1 = __atomic_load_n(c.mailbox + word, __ATOMIC_ACQUIRE);
     if (q == hipSuccess) {  // everything enqueued has retired, so the word has been stored
       unsigned long long v2 = v1;
       const clk::time_point t1 = clk::now();
       while ((uint32_t)(v2 >> 32) != c.ticket && clk::now() - t1 < std::chrono::milliseconds(2))
-        v2 = __atomic_load_n(c.mailbox, __ATOMIC_ACQUIRE);  // a store still in flight towards host memory
+        v2 = __atomic_load_n(c.mailbox + word, __ATOMIC_ACQUIRE);  // a store still in flight towards host memory
       {
         std::lock_guard<std::mutex> lk(g_slow_mu);
         g_slow_last.ticket_expected = c.ticket;
@@ -285,42 +292,74 @@ static int wait_num_rendered(ThreadCtx& c, hipStream_t stream, uint32_t* R_out) 
   }
 }
 
-// scan -> emit -> tile sort -> ranges -> blend for `cnt` instances in the binning blob `bblob` (carved for cnt.cap)
-static int enqueue_binning_and_blend(const FrameParams& fp, GeomState& g, ImageState& im, char* bblob, const Count cnt,
-                                     const float* background, float* out_color, float* out_depth, float* out_acc,
-                                     int debug, hipStream_t stream) {
-  BinningState b = BinningState::carve(bblob, (size_t)cnt.cap);
+// One binning chain: scan -> emit -> tile sort -> ranges, followed by the blend.  A whole frame is one chain over the
+// blob (phase 0).  A near/far frame (gsr_forward) runs two chains over ONE blob carved for capA + capB instances:
+// phase 1 bins the near Gaussians into slots / list positions [0, capA), phase 2 the far Gaussians that still matter
+// into [capA, capA + capB); the sort scratch is shared (the chains are ordered on the stream).
+struct Chain {
+  int phase;             // 0 whole frame, 1 near, 2 far
+  Count cnt;             // instances of this chain
+  uint32_t near_budget;  // phase 1: the near phase ends with the Gaussian in whose slot run this falls
+  uint32_t base;         // first slot / list position of this chain in the frame's slot space (phase 2: capA)
+};
+
+static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, BinningState& b, const Chain& ch,
+                         ThreadCtx& c, const float* background, float* out_color, float* out_depth, float* out_acc,
+                         int debug, hipStream_t stream) {
+  const Count cnt = ch.cnt;
   const int tiles = fp.gx * fp.gy;
   const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
   const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
   const bool key16 = tiles <= 65536;  // tile ids fit 16 bits for every image up to 4096 x 4096
-  STAGE(launch_scan_offsets(fp, g, cnt, b.chunk_first, im.ranges, b.tsort.counts, stream));
-  STAGE(launch_emit(fp, g, cnt, b.chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? b.point_list : b.ivalsB,
-                    b.inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16,
+  const bool far = ch.phase == 2;
+  const uint4* sdesc = far ? g.sdescB : g.sdesc;
+  uint32_t* chunk_first = far ? b.chunk_firstB : b.chunk_first;
+  uint32_t* point_list = b.point_list + ch.base;
+  uint8_t* inst_flag = b.inst_flag + ch.base;
+  uint2* ranges = far ? im.rangesB : im.ranges;
+  if (far)
+    STAGE(launch_scan_offsets_far(fp, g, cnt.cap, ch.base, im.live_sat, chunk_first, b.tsort.counts, c.mailbox_dev + 1,
+                                  c.ticket, stream));
+  else
+    STAGE(launch_scan_offsets(fp, g, cnt, chunk_first, im.ranges, im.rangesB, b.tsort.counts, ch.near_budget,
+                              ch.phase == 1 ? c.mailbox_dev + 2 : nullptr, c.ticket, stream));
+  STAGE(launch_emit(fp, sdesc, cnt, chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? point_list : b.ivalsB,
+                    inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16,
                     /*store_pairs=*/!key16, stream));  // 16-bit keys: the pairs are generated inside the first sort pass
-  const EmitFusion ef = {fp, g, cnt, b.chunk_first};
+  const EmitFusion ef = {fp, sdesc, cnt, chunk_first};
   // 16-bit keys and at least two passes: the last pass counts the instances of every tile into the zeroed ranges
   // instead of writing the sorted keys, and a one-workgroup scan turns the counts into ranges; otherwise the range
   // kernel reads the sorted keys as the reference's identifyTileRanges does
   static const bool ranges_from_keys = getenv("GSR_RANGES_FROM_KEYS") != nullptr;  // diagnostics / fallback
   const bool count_ranges = key16 && sort_passes(tile_bits) >= 2 && !ranges_from_keys;
-  STAGE(launch_sort_pairs(b.tkeysA, b.point_list, b.tkeysB, b.ivalsB, b.tsort, cnt, tile_bits, start_in_A,
+  STAGE(launch_sort_pairs(b.tkeysA, point_list, b.tkeysB, b.ivalsB, b.tsort, cnt, tile_bits, start_in_A,
                           /*is_depth_sort=*/false, key16, /*first_hist_done=*/true, key16 ? &ef : nullptr,
-                          count_ranges ? reinterpret_cast<uint32_t*>(im.ranges) : nullptr, stream));
+                          count_ranges ? reinterpret_cast<uint32_t*>(ranges) : nullptr, stream));
   if (count_ranges)
-    STAGE(launch_ranges_from_counts(im.ranges, tiles, stream));
+    STAGE(launch_ranges_from_counts(ranges, tiles, ch.base, stream));
   else
-    STAGE(launch_tile_ranges(b.tkeysA, cnt, im.ranges, key16, stream));
-  if (debug) {  // self-check of the binning chain: every list ordered by (depth bits, id)
+    STAGE(launch_tile_ranges(b.tkeysA, cnt, ranges, key16, ch.base, stream));
+  if (debug && ch.phase == 0) {  // self-check of the binning chain: every list ordered by (depth bits, id)
     HIP_TRY(launch_verify_sorted_lists(im.ranges, tiles, b.point_list, g.splats, g.total + 4, stream));
     uint32_t bad = 0;
     HIP_TRY(hipMemcpyAsync(&bad, g.total + 4, sizeof(bad), hipMemcpyDeviceToHost, stream));
     HIP_TRY(hipStreamSynchronize(stream));
     if (bad) return fail(GSR_ERR_HIP, "%u adjacent list entries out of (depth, id) order after the sort", bad);
   }
-  STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, stream));
+  STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, ch.phase, stream));
+  if (ch.phase == 1) STAGE(launch_live_sat(fp, im, g.total + 9, stream));
   return GSR_OK;
 }
+
+// near/far frames (gsr_set_near_far): 1 = allowed (default), 0 = never
+static std::atomic<int>& near_far_flag() {
+  static std::atomic<int> flag([] {
+    const char* e = getenv("GSR_NEAR_FAR");
+    return (e && e[0] == '0') ? 0 : 1;
+  }());
+  return flag;
+}
+static std::atomic<unsigned long long> g_near_far_forwards{0};
 
 int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn binning_alloc, void* binning_ctx,
                 gsr_alloc_fn image_alloc, void* image_ctx, int P, int D, int M, const float* background, int width,
@@ -410,6 +449,24 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const std::chrono::steady_clock::time_point t_enq = std::chrono::steady_clock::now();
   uint32_t R_host = 0;
   int key = 0;  // what the caller passes back to gsr_backward: the capacity the binning blob was carved for
+  c.last_was_near_far = false;
+  // Near/far frame (speculative forwards in the default binning mode, when the predicted instance count is at least
+  // four times the near budget): the tiles' lists are depth-ordered and a pixel stops reading its list once its
+  // transmittance falls below 1e-4 (forward.cu:380-383) -- at 2 M Gaussians / 1080p every tile is finished after
+  // ~3 % of its list, and emitting, sorting and ranging the other 97 % is most of the forward.  So the frame is binned
+  // in two chains over the Gaussians in depth order: the NEAR chain takes Gaussians until they fill a budget of
+  // `near_entries` list entries per tile on average, is sorted and blended; then only the FAR Gaussians whose tile
+  // rectangle still contains an unfinished tile are binned and blended on top (k_scan_offsets_far).  Instances that
+  // are not emitted lie, in every tile they would have gone to, behind the point where every pixel has stopped: the
+  // images, n_contrib, final_T and all gradients are bit-identical to the one-chain frame (tested), only the lists
+  // are shorter.  gsr_set_reference_rects(1) frames are never split: their lists are the reference's, whole.
+  static const long env_near_entries = getenv("GSR_NEAR_ENTRIES") ? atol(getenv("GSR_NEAR_ENTRIES")) : 320;
+  const int tiles_n = fp.gx * fp.gy;
+  const long long near_entries = c.near_entries_override >= 0 ? c.near_entries_override : env_near_entries;
+  const unsigned long long budget64 = (unsigned long long)tiles_n * (unsigned long long)near_entries;
+  const bool near_far = speculate && near_far_flag().load() && !fp.ref_rects && near_entries > 0 &&
+                        budget64 < 0x20000000ull &&
+                        (c.near_entries_override >= 0 || (unsigned long long)hint >= 4ull * budget64);  // (hook: always)
   if (!speculate) {
     const int rc = wait_num_rendered(c, stream, &R_host);
     if (rc != GSR_OK) return rc;
@@ -422,47 +479,117 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
               std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - ta).count());
     if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
     key = (int)R_host;
-    const int rc2 = enqueue_binning_and_blend(fp, g, im, bblob, Count{nullptr, key}, background, out_color, out_depth,
-                                              out_acc, debug, stream);
+    BinningState b = BinningState::carve(bblob, (size_t)key);
+    const int rc2 = enqueue_chain(fp, g, im, b, Chain{0, Count{nullptr, key}, 0xFFFFFFFFu, 0u}, c, background, out_color,
+                                  out_depth, out_acc, debug, stream);
     if (rc2 != GSR_OK) return rc2;
+    c.last_near = R_host;
+    c.last_far = 0;
   } else {
-    key = (int)hint;
-    char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
-    if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
-    int rc = enqueue_binning_and_blend(fp, g, im, bblob, Count{g.total, key}, background, out_color, out_depth, out_acc,
-                                       debug, stream);
-    if (rc != GSR_OK) return rc;
-    const std::chrono::steady_clock::time_point tw = std::chrono::steady_clock::now();
-    rc = wait_num_rendered(c, stream, &R_host);
-    if (rc != GSR_OK) return rc;
-    if (host_trace)
-      fprintf(stderr, "[gsr] speculative forward: capacity %d, R=%u, enqueue %.1f us, then waited %.1f us\n", key, R_host,
-              std::chrono::duration<double, std::micro>(tw - t_enq).count(),
-              std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count());
-    ++g_speculative_forwards;
+    bool redo = false;
+    uint32_t R_near = 0, R_far = 0;
+    if (near_far) {
+      const uint32_t budget = (uint32_t)budget64;
+      const uint32_t capA = budget + (uint32_t)tiles_n;  // the run the budget falls into ends at most one rectangle later
+      uint32_t capB = 0;
+      if (c.far_hint_override >= 0) {
+        capB = (uint32_t)c.far_hint_override;
+        c.far_hint_override = -1;
+      } else if (c.have_far) {
+        for (int k = 0; k < 4; k++) capB = c.recent_far[k] > capB ? c.recent_far[k] : capB;
+        capB = (uint32_t)std::min<unsigned long long>(0x7fffffffull - capA, (unsigned long long)capB * 5 / 4 + 65536);
+      } else {
+        capB = hint > budget ? hint - budget : 0u;  // no history: room for every instance behind the budget
+      }
+      if (capB < 4096u) capB = 4096u;
+      key = (int)(capA + capB);
+      char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
+      if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
+      BinningState b = BinningState::carve(bblob, (size_t)key);
+      int rc = enqueue_chain(fp, g, im, b, Chain{1, Count{g.total + 6, (int)capA}, budget, 0u}, c, background, out_color,
+                             out_depth, out_acc, debug, stream);
+      if (rc != GSR_OK) return rc;
+      rc = enqueue_chain(fp, g, im, b, Chain{2, Count{g.total + 8, (int)capB}, 0xFFFFFFFFu, capA}, c, background,
+                         out_color, out_depth, out_acc, debug, stream);
+      if (rc != GSR_OK) return rc;
+      const std::chrono::steady_clock::time_point tw = std::chrono::steady_clock::now();
+      if ((rc = wait_num_rendered(c, stream, &R_host)) != GSR_OK) return rc;
+      if ((rc = wait_num_rendered(c, stream, &R_near, 2)) != GSR_OK) return rc;
+      if ((rc = wait_num_rendered(c, stream, &R_far, 1)) != GSR_OK) return rc;
+      if (host_trace)
+        fprintf(stderr, "[gsr] near/far forward: capacity %u + %u, near %u, far %u of %u instances, enqueue %.1f us, "
+                        "then waited %.1f us\n", capA, capB, R_near, R_far, R_host,
+                std::chrono::duration<double, std::micro>(tw - t_enq).count(),
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count());
+      ++g_speculative_forwards;
+      ++g_near_far_forwards;
+      c.recent_far[c.recent_far_pos] = R_far;
+      c.recent_far_pos = (c.recent_far_pos + 1) & 3;
+      c.have_far = true;
+      c.last_was_near_far = true;
+      redo = R_far > capB;
+    } else {
+      key = (int)hint;
+      char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
+      if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
+      BinningState b = BinningState::carve(bblob, (size_t)key);
+      int rc = enqueue_chain(fp, g, im, b, Chain{0, Count{g.total, key}, 0xFFFFFFFFu, 0u}, c, background, out_color,
+                             out_depth, out_acc, debug, stream);
+      if (rc != GSR_OK) return rc;
+      const std::chrono::steady_clock::time_point tw = std::chrono::steady_clock::now();
+      rc = wait_num_rendered(c, stream, &R_host);
+      if (rc != GSR_OK) return rc;
+      if (host_trace)
+        fprintf(stderr, "[gsr] speculative forward: capacity %d, R=%u, enqueue %.1f us, then waited %.1f us\n", key,
+                R_host, std::chrono::duration<double, std::micro>(tw - t_enq).count(),
+                std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count());
+      ++g_speculative_forwards;
+      redo = R_host > (uint32_t)key;
+      R_near = R_host;
+    }
     if (R_host > 0x7fffffffu) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31 splat instances");
-    if (R_host > (uint32_t)key) {  // misprediction: the clamped results are discarded, the chain runs again, exact
+    if (redo) {  // misprediction: the clamped results are discarded and the frame is binned again, in one exact chain
       ++g_speculation_overflows;
       key = (int)R_host;
-      // k_scan_offsets runs a second time: its tile ticket and look-back status words (cleared by k_preprocess for
-      // the first run) must be zero again
-      HIP_TRY(hipMemsetAsync(g.dsort.tickets() + 4, 0, sizeof(uint32_t), stream));
-      HIP_TRY(hipMemsetAsync(g.dsort.scan_status(), 0, sizeof(unsigned long long) * (((size_t)P + SCAN_TILE - 1) / SCAN_TILE),
-                             stream));
-      bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
+      // the scans run a second time: their tile tickets, look-back status words and the near-budget marker (cleared by
+      // k_preprocess for the first run) must be zero again
+      const size_t nscan = ((size_t)P + SCAN_TILE - 1) / SCAN_TILE;
+      HIP_TRY(hipMemsetAsync(g.dsort.tickets() + 4, 0, 2 * sizeof(uint32_t), stream));
+      HIP_TRY(hipMemsetAsync(g.dsort.scan_status(), 0, sizeof(unsigned long long) * 2 * nscan, stream));  // both scans'
+      HIP_TRY(hipMemsetAsync(g.total + 11, 0, sizeof(uint32_t), stream));
+      char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
       if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
-      rc = enqueue_binning_and_blend(fp, g, im, bblob, Count{nullptr, key}, background, out_color, out_depth, out_acc,
-                                     debug, stream);
+      BinningState b = BinningState::carve(bblob, (size_t)key);
+      const int rc = enqueue_chain(fp, g, im, b, Chain{0, Count{nullptr, key}, 0xFFFFFFFFu, 0u}, c, background, out_color,
+                                   out_depth, out_acc, debug, stream);
       if (rc != GSR_OK) return rc;
+      c.last_was_near_far = false;
+      R_near = R_host;
+      R_far = 0;
     }
+    c.last_near = R_near;
+    c.last_far = R_far;
   }
-  c.recent[c.recent_pos] = R_host;
+  c.recent[c.recent_pos] = R_host;  // (all instances of the frame, emitted or not: what a one-chain frame needs)
   c.recent_pos = (c.recent_pos + 1) & 3;
-  c.last_R = R_host;
+  c.last_R = c.last_near + c.last_far;  // the instances this forward emitted, sorted and ranged
   return key;
 }
 
 int gsr_last_num_rendered(void) { return (int)g_ctx.last_R; }
+int gsr_set_near_far(int on) { return near_far_flag().exchange(on != 0 ? 1 : 0); }
+int gsr_near_far(void) { return near_far_flag().load(); }
+int gsr_last_near_far(unsigned* near_instances, unsigned* far_instances) {
+  if (near_instances) *near_instances = g_ctx.last_near;
+  if (far_instances) *far_instances = g_ctx.last_far;
+  return g_ctx.last_was_near_far ? 1 : 0;
+}
+void gsr_set_near_far_hints(long long near_entries_per_tile, long long far_capacity) {
+  g_ctx.near_entries_override = near_entries_per_tile < 0 ? -1 : near_entries_per_tile;
+  g_ctx.far_hint_override = far_capacity < 0 ? -1 : (far_capacity > 0x7fffffffll ? 0x7fffffffll : far_capacity);
+  if (far_capacity < 0) g_ctx.have_far = false;  // forget the far history as well
+}
+unsigned long long gsr_near_far_forwards(void) { return g_near_far_forwards.load(); }
 long long gsr_set_binning_capacity_hint(long long capacity) {
   const long long prev = g_ctx.hint_override;
   g_ctx.hint_override = capacity < 0 ? -1 : (capacity > 0x7fffffffll ? 0x7fffffffll : capacity);
@@ -674,6 +801,7 @@ int gsr_image_view_of(char* image_buffer, int width, int height, gsr_image_view*
   out->final_T = im.final_T;
   out->n_contrib = im.n_contrib;
   out->quad_last = im.quad_last;
+  out->ranges_far = reinterpret_cast<const uint32_t*>(im.rangesB);
   return GSR_OK;
 }
 

@@ -76,20 +76,25 @@ inline size_t depth_sort_tile(size_t n) {
 struct DepthSortScratch {
   uint32_t* words;
   size_t nwords;
-  size_t scan_off;  // word offset of the scan's status array
+  size_t scan_off;   // word offset of the scan's status array
+  size_t scanB_off;  // ... of the second-phase scan's (k_scan_offsets_far)
   __host__ __device__ uint32_t* ghist() const { return words; }           // [4][256]
-  __host__ __device__ uint32_t* tickets() const { return words + 1024; }  // [0..3] sort passes, [4] scan (+ padding)
+  __host__ __device__ uint32_t* tickets() const { return words + 1024; }  // [0..3] sort passes, [4] scan, [5] far scan
   __host__ __device__ uint32_t* status(int pass, int ntiles) const {      // [4][ntiles][256]
     return words + 1088 + (size_t)pass * ntiles * 256;
   }
   __host__ __device__ unsigned long long* scan_status() const {           // [ceil(n / SCAN_TILE)]
     return reinterpret_cast<unsigned long long*>(words + scan_off);
   }
+  __host__ __device__ unsigned long long* scanB_status() const {          // [ceil(n / SCAN_TILE)]
+    return reinterpret_cast<unsigned long long*>(words + scanB_off);
+  }
   static void carve(Carver& c, size_t n, DepthSortScratch& s) {
     const size_t ntiles = (n + depth_sort_tile(n) - 1) / depth_sort_tile(n);
     const size_t nscan = (n + SCAN_TILE - 1) / SCAN_TILE;
     s.scan_off = 1088 + 4 * ntiles * 256;  // even: the 64-bit status words are 8-byte aligned
-    s.nwords = s.scan_off + 2 * nscan;
+    s.scanB_off = s.scan_off + 2 * nscan;
+    s.nwords = s.scanB_off + 2 * nscan;
     s.words = c.take<uint32_t>(s.nwords);
   }
 };
@@ -101,7 +106,12 @@ struct GeomState {
   uint32_t* point_offsets;  // inclusive scan of the tile counts in Gaussian-id order (= the reference's array);
                             // not used by this pipeline: filled only by a debug forward (for the views)
   uint8_t* clamped;         // bit0..2
-  uint32_t* total;          // [1] num_rendered, device side
+  uint32_t* total;          // [64] device-side counters: [0] num_rendered (all instances of all Gaussians), [2] touched
+                            // Gaussians (backward), [4] order violations (debug self-check); near/far frames (api.hip):
+                            // [6] instances of the near phase, [7] depth-order index of the first far Gaussian,
+                            // [8] instances of the far phase, [9] tiles still live after the near phase, [10] far
+                            // Gaussians emitted, [11] scan tile in which the near budget was crossed (+1; 0 = not yet),
+                            // [12] 1 = this frame was binned near/far
   uint2* slotinfo;          // {first slot of the Gaussian's instance run, x0 | y0 << 10 | rect_width << 20}
   uint2* gpack;             // {tiles_touched, packed rect} per Gaussian: ONE 8-byte gather in depth order (the only
                             // copy of the tile counts)
@@ -113,6 +123,7 @@ struct GeomState {
                             //   x = first instance slot (exclusive scan in depth order; sdesc[P].x = R),
                             //   y = Gaussian id, z = packed tile rect x0 | y0 << 10 | width << 20,
                             //   w = ceil(2^32 / width) (exact division by multiply-high)
+  uint4* sdescB;            // [P+1] far phase: the descriptors of the far Gaussians that are emitted, compacted
   uint8_t* touched;         // [P] 1 = the blend backward wrote at least one gradient record for this Gaussian
   uint32_t* tlist;          // [P] compacted ids of touched Gaussians (backward); count in total[2]
   DepthSortScratch dsort;
@@ -132,6 +143,7 @@ struct GeomState {
     g.dkeysB = c.take<uint32_t>(P);
     g.dvalsB = c.take<uint32_t>(P);
     g.sdesc = c.take<uint4>(P + 1);
+    g.sdescB = c.take<uint4>(P + 1);
     g.touched = c.take<uint8_t>(P);
     g.tlist = c.take<uint32_t>(P);
     DepthSortScratch::carve(c, P, g.dsort);
@@ -147,6 +159,10 @@ struct ImageState {
   float* final_T;       // [H*W]
   uint32_t* n_contrib;  // [H*W]
   uint32_t* tile_order; // [tiles] backward only: tile ids by descending length of the list walk (k_tile_order)
+  uint2* rangesB;       // [tiles] near/far frames: the tile's second (far) list segment; (0, 0) otherwise.  A tile's
+                        // list is ranges[t] followed by rangesB[t]; list positions (n_contrib, quad_last) count through
+  uint8_t* quad_done;   // [tiles][4] near/far frames: 1 = every pixel of the quad was finished by the near phase
+  uint32_t* live_sat;   // [(gy+1)(gx+1)] summed-area table of the tiles still live after the near phase
   static ImageState carve(char* blob, int W, int H, size_t* bytes = nullptr) {
     Carver c(blob);
     ImageState s;
@@ -157,6 +173,9 @@ struct ImageState {
     s.final_T = c.take<float>(N);
     s.n_contrib = c.take<uint32_t>(N);
     s.tile_order = c.take<uint32_t>(tiles);
+    s.rangesB = c.take<uint2>(tiles);
+    s.quad_done = c.take<uint8_t>(tiles * 4);
+    s.live_sat = c.take<uint32_t>((size_t)((W + TILE - 1) / TILE + 1) * ((H + TILE - 1) / TILE + 1));
     if (bytes) *bytes = align_up(c.off) + ALIGN;
     return s;
   }
@@ -179,6 +198,7 @@ struct BinningState {
   float4* grad_inst;     // [R][3], aliases tkeysA..tsort
   uint8_t* inst_flag;    // [R] 1 = grad_inst[slot] was written by the blend backward
   uint32_t* chunk_first; // [R/EMIT_CHUNK + 2] depth-order index of the Gaussian covering slot k*EMIT_CHUNK
+  uint32_t* chunk_firstB; // [R/EMIT_CHUNK + 2] the same for the far phase of a near/far frame (index into sdescB)
   static BinningState carve(char* blob, size_t R, size_t* bytes = nullptr) {
     Carver c(blob);
     BinningState b;
@@ -195,6 +215,7 @@ struct BinningState {
     c.off = sort_end > g.off ? sort_end : g.off;
     b.inst_flag = c.take<uint8_t>(R);
     b.chunk_first = c.take<uint32_t>(R / EMIT_CHUNK + 2);
+    b.chunk_firstB = c.take<uint32_t>(R / EMIT_CHUNK + 2);
     if (bytes) *bytes = align_up(c.off) + ALIGN;
     return b;
   }
@@ -230,14 +251,18 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
                              hipStream_t s);
 hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
 hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint2* ranges,
-                               uint32_t* counts0, hipStream_t s);
-hipError_t launch_emit(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint32_t* tkeys_out,
+                               uint2* rangesB, uint32_t* counts0, uint32_t near_budget,
+                               unsigned long long* publish_near, uint32_t ticket, hipStream_t s);
+hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, int capB, uint32_t slot_base, const uint32_t* sat,
+                                   uint32_t* chunk_firstB, uint32_t* counts0, unsigned long long* publish,
+                                   uint32_t ticket, hipStream_t s);
+hipError_t launch_emit(const FrameParams& fp, const uint4* sdesc, Count R, uint32_t* chunk_first, uint32_t* tkeys_out,
                        uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_mask0, bool key16,
                        bool store_pairs, hipStream_t s);
 // what k_emit_scatter (the tile sort's first pass with the pairs generated in place) needs from the emitter's side
 struct EmitFusion {
   FrameParams fp;
-  GeomState g;
+  const uint4* sdesc;  // the emitted Gaussians' descriptors in depth order (GeomState::sdesc, or sdescB in a far phase)
   Count R;
   const uint32_t* chunk_first;
 };
@@ -254,12 +279,13 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
                              hipStream_t s);
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
                              int n, const uint32_t* ghist, hipStream_t s);
-hipError_t launch_ranges_from_counts(uint2* ranges, int T, hipStream_t s);
+hipError_t launch_ranges_from_counts(uint2* ranges, int T, uint32_t list_base, hipStream_t s);
 hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t* point_list, const float4* splats,
                                       uint32_t* violations, hipStream_t s);
-hipError_t launch_tile_ranges(const uint32_t* tile_ids, Count R, uint2* ranges, bool key16, hipStream_t s);
+hipError_t launch_tile_ranges(const uint32_t* tile_ids, Count R, uint2* ranges, bool key16, uint32_t list_base, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
-                                float* out_color, float* out_depth, float* out_acc, hipStream_t s);
+                                float* out_color, float* out_depth, float* out_acc, int phase, hipStream_t s);
+hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, hipStream_t s);
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                  const float* dL_dpix, const float* dL_dacc, hipStream_t s);
 hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningState b, const int* radii,

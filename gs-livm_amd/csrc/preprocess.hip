@@ -39,6 +39,12 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t v) {
   return v;
 }
 
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
 // Inclusive scan across the 64 lanes of a wave.
 __device__ __forceinline__ uint32_t wave_incl_scan_u32(uint32_t v, int lane) {
 #pragma unroll
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     radii_out[idx] = radius;  // the caller's array, or the blob's own when it passed none (launcher)
     g.gpack[idx] = make_uint2(tiles, tiles ? rect_packed : 0u);
     g.touched[idx] = 0;  // backward bookkeeping starts clean (the backward clears what it sets)
-    if (idx == 0) g.total[2] = 0u;
+    if (idx == 0) { g.total[2] = 0u; g.total[11] = 0u; }  // ([11]: no near budget crossed yet, k_scan_offsets)
     // (key, value) pairs of the per-Gaussian depth sort; Gaussians without instances sort to the end
     g.dkeysA[idx] = dkey;
     g.order[idx] = (uint32_t)idx;
@@ -492,22 +498,47 @@ __global__ __launch_bounds__(1024) void k_point_offsets(const int P, const uint2
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned long long SC_GLOBAL = 2ull << 32, SC_LOCAL = 1ull << 32;
 
+// `budget` < 0xFFFFFFFF (near/far frames, api.hip): only the NEAR Gaussians -- those whose first slot lies below the
+// budget -- get descriptors, slots and chunk entries; the Gaussian in whose run the budget falls ends the near phase:
+// it publishes the phase's instance count (total[6]) and the depth-order index of the first far Gaussian (total[7]),
+// and the scan tile it sits in (total[11]): scan tiles beyond it have nothing to do and leave at once (they publish a
+// saturated prefix so that the look-back of still later tiles ends there).
 __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp, GeomState g, const Count cnt,
                                                             uint32_t* __restrict__ chunk_first,
-                                                            uint2* __restrict__ ranges,
-                                                            uint32_t* __restrict__ counts0, const size_t ncounts0) {
+                                                            uint2* __restrict__ ranges, uint2* __restrict__ rangesB,
+                                                            uint32_t* __restrict__ counts0, const size_t ncounts0,
+                                                            const uint32_t budget,
+                                                            unsigned long long* __restrict__ publish_near,
+                                                            const uint32_t ticket) {
   __shared__ uint32_t wtot[PRE_BLOCK / 64];
   __shared__ uint32_t s_tile, s_prefix;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int R = cnt.get();  // min(num_rendered, capacity): slots beyond the capacity are never emitted (api.hip)
+  const bool split = budget != 0xFFFFFFFFu;
+  // R: the count this chain works with.  Whole frame: min(num_rendered, capacity) (slots beyond the capacity are never
+  // emitted, api.hip).  Near phase: `cnt` points at the near count this very kernel publishes, so the frame's total
+  // comes from total[0].
+  const uint32_t R_total = split ? g.total[0] : (uint32_t)cnt.get();
+  const int R = (int)R_total;
+  if (blockIdx.x == 0 && tid == 0) g.total[12] = split ? 1u : 0u;  // marks the frame for the views (api.hip)
   // side job: (0, 0) for the tiles no instance lands in
-  for (int t = blockIdx.x * PRE_BLOCK + tid; t < fp.gx * fp.gy; t += gridDim.x * PRE_BLOCK)
+  for (int t = blockIdx.x * PRE_BLOCK + tid; t < fp.gx * fp.gy; t += gridDim.x * PRE_BLOCK) {
     ranges[t] = make_uint2(0u, 0u);
+    rangesB[t] = make_uint2(0u, 0u);
+  }
   // side job: clear the digit counts of the tile sort's first pass (k_emit accumulates them while emitting)
   for (size_t q = (size_t)blockIdx.x * PRE_BLOCK + tid; q < ncounts0; q += (size_t)gridDim.x * PRE_BLOCK) counts0[q] = 0u;
   if (tid == 0) s_tile = atomicAdd(g.dsort.tickets() + 4, 1u);  // every lower tile is already running
   __syncthreads();
   const uint32_t tile = s_tile;
+  if (split) {
+    const uint32_t crossed = __hip_atomic_load(g.total + 11, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (crossed != 0u && tile + 1u > crossed) {  // the near phase ended in an earlier tile
+      if (tid == 0)
+        __hip_atomic_store(g.dsort.scan_status() + tile, SC_GLOBAL | 0xFFFFFFFFull, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
   const int i0 = (int)(tile * SCAN_TILE) + tid * SCAN_ITEMS;
   uint32_t id[SCAN_ITEMS], n[SCAN_ITEMS], rect[SCAN_ITEMS];
   if (i0 + SCAN_ITEMS <= fp.P) {
@@ -552,41 +583,197 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
           __builtin_amdgcn_s_sleep(1);
           continue;
         }
-        prefix += wave_sum_u32(lane <= fg ? (uint32_t)v : 0u);
+        {  // saturating: a tile that left early published 0xFFFFFFFF ("beyond the near budget")
+          const unsigned long long add = wave_sum_u64(lane <= fg ? (unsigned long long)(uint32_t)v : 0ull) + prefix;
+          prefix = add > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)add;
+        }
         if (fg < 64) break;
         base -= 64;
       }
-      if (lane == 0)
-        __hip_atomic_store(st + tile, SC_GLOBAL | (unsigned long long)(prefix + agg), __ATOMIC_RELAXED,
+      if (lane == 0) {
+        const unsigned long long inc_all = (unsigned long long)prefix + agg;
+        __hip_atomic_store(st + tile, SC_GLOBAL | (inc_all > 0xFFFFFFFFull ? 0xFFFFFFFFull : inc_all), __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
+      }
     }
     if (lane == 0) s_prefix = prefix;
   }
   __syncthreads();
+  if (split && s_prefix >= budget) return;  // the whole tile lies beyond the near phase (status already published)
   uint32_t off = s_prefix + inc - sum;  // exclusive offset of this thread's first Gaussian
   for (int k = 0; k < w; k++) off += wtot[k];
   if (i0 >= fp.P) return;
   uint32_t offs[SCAN_ITEMS], inv[SCAN_ITEMS];
-  const uint32_t last_chunk = (uint32_t)((R + EMIT_CHUNK - 1) / EMIT_CHUNK);
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++) {
     offs[k] = off;
     const uint32_t rw = rect[k] >> 20;
     inv[k] = n[k] ? 0xFFFFFFFFu / rw + 1u : 0u;  // ceil(2^32 / rw) for rw > 1 (wraps to 0 for rw == 1: k_emit)
-    if (i0 + k < fp.P && n[k]) {
+    if (i0 + k < fp.P && n[k] && off < budget) {
       const uint32_t end = off + n[k];
       g.slotinfo[id[k]] = make_uint2(off, rect[k]);
-      const uint32_t end_c = end < (uint32_t)R ? end : (uint32_t)R;  // (R < num_rendered only in an overflowed frame)
+      // this chain's last slot: the frame's (clamped to the capacity in an overflowed speculative frame) or, in a
+      // near/far frame, the end of the run the budget falls into
+      const bool last_near = split && (end >= budget || end == R_total);
+      const uint32_t Rc = split ? (last_near ? end : 0xFFFFFFFFu) : (uint32_t)R;
+      const uint32_t end_c = end < Rc ? end : Rc;
       for (uint32_t c = (off + EMIT_CHUNK - 1) / EMIT_CHUNK; (unsigned long long)c * EMIT_CHUNK < end_c; c++)
         chunk_first[c] = (uint32_t)(i0 + k);
-      if (off < (uint32_t)R && end >= (uint32_t)R) chunk_first[last_chunk] = (uint32_t)(i0 + k);
+      if (split ? last_near : (off < (uint32_t)R && end >= (uint32_t)R))
+        chunk_first[(size_t)(((split ? end : (uint32_t)R) + EMIT_CHUNK - 1) / EMIT_CHUNK)] = (uint32_t)(i0 + k);
+      if (last_near) {  // exactly one Gaussian of the frame
+        g.total[6] = end;
+        g.total[7] = (uint32_t)(i0 + k) + 1u;
+        g.sdesc[i0 + k + 1] = make_uint4(end, 0u, 0u, 0u);  // sentinel behind the last near descriptor (.x is what counts)
+        __hip_atomic_store(g.total + 11, tile + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (publish_near)  // the host's copy of the near count (statistics only: the near capacity cannot overflow)
+          __hip_atomic_store(publish_near, ((unsigned long long)ticket << 32) | end, __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
     off += n[k];
   }
 #pragma unroll
   for (int k = 0; k < SCAN_ITEMS; k++)
-    if (i0 + k < fp.P) g.sdesc[i0 + k] = make_uint4(offs[k], id[k], rect[k], inv[k]);  // 256 contiguous bytes per thread
-  if (i0 + SCAN_ITEMS >= fp.P) g.sdesc[fp.P] = make_uint4(off, 0u, 0u, 0u);  // sentinel: .x = R
+    if (i0 + k < fp.P && offs[k] < budget)
+      g.sdesc[i0 + k] = make_uint4(offs[k], id[k], rect[k], inv[k]);  // 256 contiguous bytes per thread
+  if (!split && i0 + SCAN_ITEMS >= fp.P) g.sdesc[fp.P] = make_uint4(off, 0u, 0u, 0u);  // sentinel: .x = R
+  if (split && R_total == 0u && i0 == 0) {  // nothing to bin at all
+    g.total[6] = 0u;
+    g.total[7] = 0u;
+    if (publish_near)
+      __hip_atomic_store(publish_near, (unsigned long long)ticket << 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+// Far phase of a near/far frame (api.hip).  The near phase has been binned and blended; `sat` is the summed-area table
+// of the tiles that still have an unfinished pixel.  A far Gaussian (depth-order index >= total[7]) is emitted -- with
+// its whole tile rectangle, so that every slot rule of the near phase holds -- iff its rectangle contains a live tile:
+// a tile that is finished can receive nothing from it (every pixel has stopped, forward.cu:380-383), exactly as if
+// its instances sat in the part of the list the reference never reads.  One launch, look-back scan over the same
+// 4096-Gaussian tiles of the depth order with a (slots, emitted Gaussians) pair in the 64-bit status word
+// [flag:2 | Gaussians:30 | slots:32]; the emitted Gaussians' descriptors are written COMPACTED (sdescB) because the
+// emitters stage the descriptors between two chunk boundaries in LDS and assume that each owns at least one slot.
+// Slots are numbered from `slot_base` (the near phase's capacity) in the frame's one slot space, so gradient records,
+// flags and slotinfo need no notion of a phase.  The last tile publishes the phase's totals (total[8], total[10],
+// the sentinel, and the host's second mailbox word).
+constexpr unsigned long long SF_GLOBAL = 2ull << 62, SF_LOCAL = 1ull << 62, SF_MASK = (1ull << 62) - 1ull;
+
+__global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets_far(const FrameParams fp, GeomState g, const int capB,
+                                                                const uint32_t slot_base,
+                                                                const uint32_t* __restrict__ sat,
+                                                                uint32_t* __restrict__ chunk_firstB,
+                                                                uint32_t* __restrict__ counts0, const size_t ncounts0,
+                                                                unsigned long long* __restrict__ publish,
+                                                                const uint32_t ticket) {
+  __shared__ unsigned long long wtot[PRE_BLOCK / 64];
+  __shared__ uint32_t s_tile;
+  __shared__ unsigned long long s_prefix;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  // side job: clear the digit counts of the far tile sort's first pass
+  for (size_t q = (size_t)blockIdx.x * PRE_BLOCK + tid; q < ncounts0; q += (size_t)gridDim.x * PRE_BLOCK) counts0[q] = 0u;
+  if (tid == 0) s_tile = atomicAdd(g.dsort.tickets() + 5, 1u);
+  __syncthreads();
+  const uint32_t tile = s_tile;
+  const uint32_t ntiles = gridDim.x;
+  const uint32_t iA = g.total[7], live_tiles = g.total[9];
+  unsigned long long* st = g.dsort.scanB_status();
+  const int i0 = (int)(tile * SCAN_TILE) + tid * SCAN_ITEMS;
+  const bool idle = live_tiles == 0u || (uint32_t)(tile + 1u) * SCAN_TILE <= iA;  // workgroup-uniform
+  uint32_t id[SCAN_ITEMS], n[SCAN_ITEMS], rect[SCAN_ITEMS];
+  unsigned long long sum = 0ull;  // (emitted Gaussians << 32) | slots of this thread's items
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) { id[k] = 0xFFFFFFFFu; n[k] = 0u; rect[k] = 0u; }
+  if (!idle) {
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++)
+      if (i0 + k < fp.P && (uint32_t)(i0 + k) >= iA) id[k] = g.order[i0 + k];
+    const int sw = fp.gx + 1;
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; k++) {
+      if (id[k] == 0xFFFFFFFFu) continue;
+      const uint2 gp = g.gpack[id[k]];
+      if (!gp.x) continue;
+      const int x0 = (int)(gp.y & 1023u), y0 = (int)((gp.y >> 10) & 1023u), rw = (int)(gp.y >> 20);
+      const int x1 = x0 + rw, y1 = y0 + (int)(gp.x / (uint32_t)rw);
+      const uint32_t live = sat[y1 * sw + x1] - sat[y0 * sw + x1] - sat[y1 * sw + x0] + sat[y0 * sw + x0];
+      if (live) {
+        n[k] = gp.x;
+        rect[k] = gp.y;
+        sum += (1ull << 32) | gp.x;
+      }
+    }
+  }
+  // inclusive scan of the packed pair over the workgroup (slots < 2^31 per frame: no carry into the upper half)
+  unsigned long long inc = sum;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned long long t = __shfl_up(inc, o, 64);
+    if (lane >= o) inc += t;
+  }
+  if (lane == 63) wtot[w] = inc;
+  __syncthreads();
+  const unsigned long long agg = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+  auto pack = [](unsigned long long v) { return ((v >> 32) << 32) | (v & 0xFFFFFFFFull); };  // identity (documentation)
+  if (w == 0) {
+    unsigned long long prefix = 0ull;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(st, SF_GLOBAL | pack(agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(st + tile, SF_LOCAL | pack(agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int base = (int)tile - 1;
+      for (;;) {
+        const int t = base - lane;
+        const unsigned long long v =
+            t >= 0 ? __hip_atomic_load(st + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SF_GLOBAL;
+        const uint32_t flag = (uint32_t)(v >> 62);
+        const uint64_t mg = __ballot(flag == 2u), mn = __ballot(flag == 0u);
+        const int fg = mg ? __builtin_ctzll(mg) : 64;
+        const uint64_t nearer = fg == 64 ? ~0ull : ((1ull << fg) - 1ull);
+        if (mn & nearer) {
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        prefix += wave_sum_u64(lane <= fg ? (v & SF_MASK) : 0ull);
+        if (fg < 64) break;
+        base -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(st + tile, SF_GLOBAL | (prefix + agg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_prefix = prefix;
+  }
+  __syncthreads();
+  unsigned long long run = s_prefix + inc - sum;  // exclusive (Gaussians, slots) before this thread's first item
+  for (int k = 0; k < w; k++) run += wtot[k];
+  if (tile == ntiles - 1u && tid == PRE_BLOCK - 1) {  // the frame's last item: totals of the far phase
+    const unsigned long long tot = s_prefix + agg;
+    const uint32_t RB = (uint32_t)(tot & 0xFFFFFFFFull), nG = (uint32_t)(tot >> 32);
+    g.total[8] = RB;
+    g.total[10] = nG;
+    g.sdescB[nG] = make_uint4(RB, 0u, 0u, 0u);  // sentinel: .x = the far phase's instance count
+    if (nG && RB <= (uint32_t)capB) chunk_firstB[(size_t)((RB + EMIT_CHUNK - 1) / EMIT_CHUNK)] = nG - 1u;  // (as k_scan_offsets)
+    if (publish)
+      __hip_atomic_store(publish, ((unsigned long long)ticket << 32) | RB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+  if (idle) return;
+  const uint32_t RB_cap = (uint32_t)capB;
+#pragma unroll
+  for (int k = 0; k < SCAN_ITEMS; k++) {
+    if (!n[k]) continue;
+    const uint32_t off = (uint32_t)(run & 0xFFFFFFFFull), j = (uint32_t)(run >> 32);
+    const uint32_t rw = rect[k] >> 20;
+    const uint32_t end = off + n[k];
+    g.sdescB[j] = make_uint4(off, id[k], rect[k], 0xFFFFFFFFu / rw + 1u);
+    g.slotinfo[id[k]] = make_uint2(slot_base + off, rect[k]);
+    // (a frame whose far count exceeds the capacity is discarded by the host: keep the chunk table in bounds)
+    const uint32_t end_c = end < RB_cap ? end : RB_cap;
+    for (uint32_t c = (off + EMIT_CHUNK - 1) / EMIT_CHUNK; (unsigned long long)c * EMIT_CHUNK < end_c; c++)
+      chunk_firstB[c] = j;
+    if (off < RB_cap && end > RB_cap)  // overflowed frame: the emitters stop at the capacity, inside this run
+      chunk_firstB[(size_t)((RB_cap + EMIT_CHUNK - 1) / EMIT_CHUNK)] = j;
+    run += (1ull << 32) | n[k];
+  }
 }
 
 // Staging and slot walk of the emitters, as device functions (k_emit_scatter runs them twice per workgroup).
@@ -595,14 +782,14 @@ struct EmitStage {
 };
 
 // descriptors of the Gaussians covering slots [c0, c1) of emit chunk `e` -> LDS; returns their count S
-__device__ __forceinline__ int emit_stage(const GeomState& g, const uint32_t* __restrict__ chunk_first, int e,
+__device__ __forceinline__ int emit_stage(const uint4* __restrict__ sdesc, const uint32_t* __restrict__ chunk_first, int e,
                                           uint32_t c1, int R, int tid, EmitStage& st) {
   const int i0 = (int)chunk_first[e];
   int i1 = (int)chunk_first[e + 1];
-  if (c1 < (uint32_t)R && g.sdesc[i1].x >= c1) i1--;  // the Gaussian covering slot c1 starts exactly there
+  if (c1 < (uint32_t)R && sdesc[i1].x >= c1) i1--;    // the Gaussian covering slot c1 starts exactly there
   const int S = i1 - i0 + 1;                          // <= EMIT_CHUNK + 1: every staged Gaussian owns >= 1 slot
   for (int j = tid; j <= S; j += 256) {               // s_off[S] = start of the first run beyond this chunk
-    const uint4 d = g.sdesc[i0 + j];                  // (sdesc has P + 1 entries)
+    const uint4 d = sdesc[i0 + j];                    // (the descriptor arrays have P + 1 entries)
     st.s_off[j] = d.x;
     if (j < S) {
       st.s_id[j] = d.y;
@@ -648,7 +835,7 @@ __device__ __forceinline__ void emit_walk8(uint32_t t0, uint32_t c1, int S, cons
 // the unsorted pairs are never written to or read back from HBM (2 x 6 bytes per instance).  The digit counts the
 // scatter needs were accumulated by the count-only emitter (k_emit<K, false>) and scanned in between.
 template <bool ARANK>
-__global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, GeomState g, const Count cnt,
+__global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, const uint4* __restrict__ sdesc, const Count cnt,
                                                       const uint32_t* __restrict__ chunk_first,
                                                       uint16_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                       const int nbits0, const uint32_t* __restrict__ counts,
@@ -673,7 +860,7 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, Geom
     const bool live = c0 < (uint32_t)R;  // workgroup-uniform
     const uint32_t c1 = c0 + EMIT_CHUNK < (uint32_t)R ? c0 + EMIT_CHUNK : (uint32_t)R;
     int S = 0;
-    if (live) S = emit_stage(g, chunk_first, e, c1, R, tid, sm.st);
+    if (live) S = emit_stage(sdesc, chunk_first, e, c1, R, tid, sm.st);
     __syncthreads();
     const uint32_t t0 = c0 + (uint32_t)tid * 8u;
     if (live && t0 < c1) emit_walk8(t0, c1, S, sm.st, (uint32_t)fp.gx, tk[r], iv[r]);
@@ -713,7 +900,7 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, Geom
 
 // STORE = false: count-only emitter in front of k_emit_scatter (digit counts + inst_flag reset, no pair stores)
 template <typename K, bool STORE>
-__global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g, const Count cnt,
+__global__ __launch_bounds__(256) void k_emit(const FrameParams fp, const uint4* __restrict__ sdesc, const Count cnt,
                                               const uint32_t* __restrict__ chunk_first,
                                               K* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out,
                                               uint8_t* __restrict__ inst_flag, uint32_t* __restrict__ counts0,
@@ -726,7 +913,7 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, GeomState g,
   hist[tid] = 0;
   const uint32_t c0 = (uint32_t)blockIdx.x * EMIT_CHUNK;
   const uint32_t c1 = c0 + EMIT_CHUNK < (uint32_t)R ? c0 + EMIT_CHUNK : (uint32_t)R;
-  const int S = emit_stage(g, chunk_first, (int)blockIdx.x, c1, R, tid, st);
+  const int S = emit_stage(sdesc, chunk_first, (int)blockIdx.x, c1, R, tid, st);
   __syncthreads();
   // Each thread owns EIGHT consecutive slots: one bisection for the first, then it walks (row, col) and steps to
   // the next Gaussian when a run ends -- 4x fewer LDS round trips than a search per slot, 32-byte stores.
@@ -1227,28 +1414,39 @@ hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t 
 }
 
 hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint2* ranges,
-                               uint32_t* counts0, hipStream_t s) {
+                               uint2* rangesB, uint32_t* counts0, uint32_t near_budget,
+                               unsigned long long* publish_near, uint32_t ticket, hipStream_t s) {
   const size_t ncounts0 = (size_t)((R.cap + TSORT_TILE - 1) / TSORT_TILE) * 256;
   ProfScope ps(K_SCAN_OFFSETS, s);
   hipLaunchKernelGGL(k_scan_offsets, dim3((fp.P + SCAN_TILE - 1) / SCAN_TILE), dim3(PRE_BLOCK), 0, s, fp, g, R,
-                     chunk_first, ranges, counts0, ncounts0);
+                     chunk_first, ranges, rangesB, counts0, ncounts0, near_budget, publish_near, ticket);
   return hipGetLastError();
 }
 
-hipError_t launch_emit(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint32_t* tkeys_out,
+hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, int capB, uint32_t slot_base, const uint32_t* sat,
+                                   uint32_t* chunk_firstB, uint32_t* counts0, unsigned long long* publish,
+                                   uint32_t ticket, hipStream_t s) {
+  const size_t ncounts0 = (size_t)((capB + TSORT_TILE - 1) / TSORT_TILE) * 256;
+  ProfScope ps(K_SCAN_OFFSETS, s);
+  hipLaunchKernelGGL(k_scan_offsets_far, dim3((fp.P + SCAN_TILE - 1) / SCAN_TILE), dim3(PRE_BLOCK), 0, s, fp, g, capB,
+                     slot_base, sat, chunk_firstB, counts0, ncounts0, publish, ticket);
+  return hipGetLastError();
+}
+
+hipError_t launch_emit(const FrameParams& fp, const uint4* sdesc, Count R, uint32_t* chunk_first, uint32_t* tkeys_out,
                        uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_mask0, bool key16,
                        bool store_pairs, hipStream_t s) {
   if (R.cap <= 0) return hipSuccess;
   ProfScope ps(K_EMIT, s);
   const dim3 grid((R.cap + EMIT_CHUNK - 1) / EMIT_CHUNK);
   if (key16 && store_pairs)
-    hipLaunchKernelGGL((k_emit<uint16_t, true>), grid, dim3(256), 0, s, fp, g, R, chunk_first,
+    hipLaunchKernelGGL((k_emit<uint16_t, true>), grid, dim3(256), 0, s, fp, sdesc, R, chunk_first,
                        reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_mask0);
   else if (key16)
-    hipLaunchKernelGGL((k_emit<uint16_t, false>), grid, dim3(256), 0, s, fp, g, R, chunk_first,
+    hipLaunchKernelGGL((k_emit<uint16_t, false>), grid, dim3(256), 0, s, fp, sdesc, R, chunk_first,
                        reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_mask0);
   else
-    hipLaunchKernelGGL((k_emit<uint32_t, true>), grid, dim3(256), 0, s, fp, g, R, chunk_first, tkeys_out, ivals_out,
+    hipLaunchKernelGGL((k_emit<uint32_t, true>), grid, dim3(256), 0, s, fp, sdesc, R, chunk_first, tkeys_out, ivals_out,
                        inst_flag, counts0, digit_mask0);
   return hipGetLastError();
 }
@@ -1259,10 +1457,10 @@ hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_
                                bool arank, hipStream_t s) {
   const dim3 grid((ef.R.cap + TSORT_TILE - 1) / TSORT_TILE);
   if (arank)
-    hipLaunchKernelGGL(k_emit_scatter<true>, grid, dim3(256), 0, s, ef.fp, ef.g, ef.R, ef.chunk_first, keys_out, vals_out,
+    hipLaunchKernelGGL(k_emit_scatter<true>, grid, dim3(256), 0, s, ef.fp, ef.sdesc, ef.R, ef.chunk_first, keys_out, vals_out,
                        nbits0, counts, chunk_base, digit_total);
   else
-    hipLaunchKernelGGL(k_emit_scatter<false>, grid, dim3(256), 0, s, ef.fp, ef.g, ef.R, ef.chunk_first, keys_out,
+    hipLaunchKernelGGL(k_emit_scatter<false>, grid, dim3(256), 0, s, ef.fp, ef.sdesc, ef.R, ef.chunk_first, keys_out,
                        vals_out, nbits0, counts, chunk_base, digit_total);
   return hipGetLastError();
 }

@@ -349,7 +349,8 @@ hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
 // reference's cudaMemset at :311 -- here a side job of k_scan_offsets).  Every thread owns 16 bytes of sorted
 // keys (8 x u16 or 4 x u32) plus the key before them, so the pass over the keys runs at streaming rate.
 template <typename K>
-__global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys, const Count cnt, uint2* __restrict__ ranges) {
+__global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys, const Count cnt, uint2* __restrict__ ranges,
+                                                     const uint32_t list_base) {
   constexpr int PER = 16 / (int)sizeof(K);
   const int L = cnt.get();
   const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * PER;
@@ -370,10 +371,10 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys,
     const size_t i = i0 + j;
     if (i < (size_t)L) {
       if (k[j] != prev) {
-        if (i) ranges[prev].y = (uint32_t)i;
-        ranges[k[j]].x = (uint32_t)i;
+        if (i) ranges[prev].y = list_base + (uint32_t)i;
+        ranges[k[j]].x = list_base + (uint32_t)i;
       }
-      if (i == (size_t)L - 1) ranges[k[j]].y = (uint32_t)L;
+      if (i == (size_t)L - 1) ranges[k[j]].y = list_base + (uint32_t)L;
       prev = k[j];
     }
   }
@@ -381,11 +382,12 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys,
 
 // Ranges from the per-tile instance counts the last sort pass left in ranges[t].y (ranges[t].x still zero): one
 // workgroup scans them; tiles without instances keep the reference's (0, 0) (its cudaMemset, rasterizer_impl.cu:311).
-__global__ __launch_bounds__(1024) void k_ranges_from_counts(uint2* __restrict__ ranges, const int T) {
+__global__ __launch_bounds__(1024) void k_ranges_from_counts(uint2* __restrict__ ranges, const int T,
+                                                             const uint32_t list_base) {
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (tid == 0) carry_s = 0u;
+  if (tid == 0) carry_s = list_base;  // (the far segment of a near/far frame lives behind the near capacity)
   __syncthreads();
   for (int t0 = 0; t0 < T; t0 += 1024 * 4) {
     const int i0 = t0 + tid * 4;
@@ -410,20 +412,20 @@ __global__ __launch_bounds__(1024) void k_ranges_from_counts(uint2* __restrict__
   }
 }
 
-hipError_t launch_ranges_from_counts(uint2* ranges, int T, hipStream_t s) {
+hipError_t launch_ranges_from_counts(uint2* ranges, int T, uint32_t list_base, hipStream_t s) {
   ProfScope ps(K_TILE_RANGES, s);
-  hipLaunchKernelGGL(k_ranges_from_counts, dim3(1), dim3(1024), 0, s, ranges, T);
+  hipLaunchKernelGGL(k_ranges_from_counts, dim3(1), dim3(1024), 0, s, ranges, T, list_base);
   return hipGetLastError();
 }
 
-hipError_t launch_tile_ranges(const uint32_t* keys, Count R, uint2* ranges, bool key16, hipStream_t s) {
+hipError_t launch_tile_ranges(const uint32_t* keys, Count R, uint2* ranges, bool key16, uint32_t list_base, hipStream_t s) {
   if (R.cap <= 0) return hipSuccess;
   ProfScope ps(K_TILE_RANGES, s);
   if (key16)
     hipLaunchKernelGGL(k_tile_ranges<uint16_t>, dim3((R.cap + 2047) / 2048), dim3(256), 0, s,
-                       reinterpret_cast<const uint16_t*>(keys), R, ranges);
+                       reinterpret_cast<const uint16_t*>(keys), R, ranges, list_base);
   else
-    hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((R.cap + 1023) / 1024), dim3(256), 0, s, keys, R, ranges);
+    hipLaunchKernelGGL(k_tile_ranges<uint32_t>, dim3((R.cap + 1023) / 1024), dim3(256), 0, s, keys, R, ranges, list_base);
   return hipGetLastError();
 }
 

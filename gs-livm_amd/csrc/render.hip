@@ -179,13 +179,24 @@ __device__ __forceinline__ uint32_t quad_hits(float x, float y, float hx, float 
 // of a barrier-per-chunk design (VALU active 14 % of wave cycles).
 // quad_last[4*tile + q] = max n_contrib inside the quad: bounds the backward walk.
 // ------------------------------------------------------------------------------------------------
-template <int FW>  // quads (= waves) per workgroup: the waves never synchronise, FW only sets how many share a workgroup slot
+// PHASE (near/far frames, api.hip): 0 = the whole list in one launch.  1 = the NEAR segment of the tile's list
+// (`ranges`): a quad all of whose pixels have stopped is finished as in phase 0 and marked quad_done; any other quad
+// parks its pixels' running state in the output arrays (colour WITHOUT the background term, T, depth and silhouette
+// sums, last contributor with bit 31 = "this pixel has stopped").  2 = the FAR segment (`rangesB`), only for the quads
+// phase 1 left unfinished: the state is picked up, list positions continue behind the near segment's, and the pixels
+// are finished.  The arithmetic per pixel is the same sequence either way: images, n_contrib and final_T are bitwise
+// those of a single launch over the concatenated list.
+constexpr uint32_t STOPPED_BIT = 0x80000000u;
+
+template <int FW, int PHASE>  // FW quads (= waves) per workgroup: the waves never synchronise, FW only sets how many share a slot
 __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp, const uint2* __restrict__ ranges,
+                                                      const uint2* __restrict__ rangesB,
                                                       const uint32_t* __restrict__ point_list,
                                                       const float4* __restrict__ splats,
                                                       const float* __restrict__ bg, float* __restrict__ final_T,
                                                       uint32_t* __restrict__ n_contrib,
-                                                      uint32_t* __restrict__ quad_last, float* __restrict__ out_color,
+                                                      uint32_t* __restrict__ quad_last, uint8_t* __restrict__ quad_done,
+                                                      float* __restrict__ out_color,
                                                       float* __restrict__ out_depth, float* __restrict__ out_acc) {
   __shared__ float4 sAll[FW][3][64];  // wave-private images: no barrier anywhere in this kernel
   const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
@@ -201,12 +212,29 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
   const bool inside = px < fp.W && py < fp.H;
   const float pfx = (float)px, pfy = (float)py;
   const float qx0 = (float)qx, qy0 = (float)qy;
-  const uint2 range = ranges[tile];
+  if (PHASE == 2 && quad_done[quad]) return;  // finished by the near phase
+  const uint2 range = PHASE == 2 ? rangesB[tile] : ranges[tile];
   const int n = (int)(range.y - range.x);
+  uint32_t pos0 = 0;  // list position of this segment's first entry
+  if (PHASE == 2) {
+    const uint2 rn = ranges[tile];
+    pos0 = rn.y - rn.x;
+  }
+  const size_t pid = (size_t)fp.W * py + px;
+  const size_t N = (size_t)fp.W * fp.H;
 
   float T = 1.0f, C0 = 0.f, C1 = 0.f, C2 = 0.f, Dp = 0.f, A = 0.f;
   uint32_t last = 0;
   bool done = !inside;
+  if (PHASE == 2 && inside) {  // the state phase 1 parked
+    T = final_T[pid];
+    const uint32_t l = n_contrib[pid];
+    last = l & ~STOPPED_BIT;
+    done = (l & STOPPED_BIT) != 0u;
+    C0 = out_color[pid]; C1 = out_color[N + pid]; C2 = out_color[2 * N + pid];
+    Dp = out_depth[pid];
+    A = out_acc[pid];
+  }
   bool wave_done = __ballot(!done) == 0ull;
 
   // software pipeline: (a, b, c, hit) hold the sub-chunk about to be consumed
@@ -255,7 +283,7 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
       Dp += rc.y * wgt;
       A += wgt;
       T = ok ? test_T : T;
-      last = ok ? (uint32_t)(base + jj + 1) : last;
+      last = ok ? pos0 + (uint32_t)(base + jj + 1) : last;
     };
     if (m) {
       int j0 = __builtin_ctzll(m), j1;
@@ -288,9 +316,21 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
 
   const uint32_t wl = wave_max_u32(inside ? last : 0u);
   if (lane == 0) quad_last[quad] = wl;
+  if (PHASE == 1) {
+    const bool all_stopped = __ballot(!done) == 0ull;
+    if (lane == 0) quad_done[quad] = all_stopped ? 1 : 0;
+    if (!all_stopped) {  // park the running state for phase 2
+      if (inside) {
+        final_T[pid] = T;
+        n_contrib[pid] = last | (done ? STOPPED_BIT : 0u);
+        out_color[pid] = C0; out_color[N + pid] = C1; out_color[2 * N + pid] = C2;
+        out_depth[pid] = Dp;
+        out_acc[pid] = A;
+      }
+      return;
+    }
+  }
   if (inside) {
-    const size_t pid = (size_t)fp.W * py + px;
-    const size_t N = (size_t)fp.W * fp.H;
     final_T[pid] = T;
     n_contrib[pid] = last;
     out_color[pid] = C0 + T * bg[0];
@@ -313,7 +353,8 @@ __global__ __launch_bounds__(256) void k_blend_backward(
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const uint2* __restrict__ slotinfo,
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dacc, float4* __restrict__ grad_inst,
-    uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_order) {
+    uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_order,
+    const uint2* __restrict__ rangesB) {
   constexpr int LW = BCHUNK / 64;  // loader waves
   // one 48-byte image per staged entry -- (x, y, conic.x', conic.y' | conic.z', opacity, r, g | b, conic) with the
   // primed terms pre-scaled for exp2 -- so a visit
@@ -332,7 +373,10 @@ __global__ __launch_bounds__(256) void k_blend_backward(
                  ql3 = quad_last_in[4 * tile + 3];
   const int n = (int)max(max(ql0, ql1), max(ql2, ql3));  // entries [0, n) of the tile's list can carry gradient
   if (n == 0) return;
-  const uint32_t rbase = ranges[tile].x;
+  // the tile's list = its near segment followed by its far segment (near/far frames; (0, 0) otherwise)
+  const uint2 rng = ranges[tile];
+  const uint32_t rbase = rng.x, rbaseB = rangesB[tile].x;
+  const int lenA = (int)(rng.y - rng.x);
   const int px = tile_x * TILE + (w & 1) * 8 + (lane & 7);
   const int py = tile_y * TILE + (w >> 1) * 8 + (lane >> 3);
   const bool inside = px < fp.W && py < fp.H;
@@ -361,7 +405,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
     uint32_t hits = 0;
     if (stager && k < n) {
       const int pos = n - 1 - k;
-      const uint32_t id = point_list[rbase + pos];
+      const uint32_t id = pos < lenA ? point_list[rbase + pos] : point_list[rbaseB + (uint32_t)(pos - lenA)];
       const float4 a = splats[(size_t)id * SPLAT_F4 + 0];
       const float4 b = splats[(size_t)id * SPLAT_F4 + 1];
       const float4 c = splats[(size_t)id * SPLAT_F4 + 2];
@@ -555,7 +599,8 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const uint2* __restrict__ slotinfo,
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
     const float* __restrict__ dL_dpix, const float* __restrict__ dL_dacc, float* __restrict__ grad_inst,
-    uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_order) {
+    uint8_t* __restrict__ inst_flag, uint8_t* __restrict__ touched, const uint32_t* __restrict__ tile_order,
+    const uint2* __restrict__ rangesB) {
   __shared__ float4 sE[TW][64][3];  // (x, y, A', B' | C', opacity, r, g | b, -, -, -) per staged entry
   __shared__ uint32_t sSlot[TW][64], sId[TW][64];
   const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
@@ -566,7 +611,10 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
   const int n = (int)max(max(ql0, ql1), max(ql2, ql3));  // entries [0, n) of the tile's list can carry gradient
   if (n == 0) return;
   const int tile_x = tile % fp.gx, tile_y = tile / fp.gx;
-  const uint32_t rbase = ranges[tile].x;
+  // the tile's list = its near segment followed by its far segment (near/far frames; (0, 0) otherwise)
+  const uint2 rng = ranges[tile];
+  const uint32_t rbase = rng.x, rbaseB = rangesB[tile].x;
+  const int lenA = (int)(rng.y - rng.x);
   const int px = tile_x * TILE + (lane & 15);
   const float pfx = (float)px;
   const float tx0 = (float)(tile_x * TILE), ty0 = (float)(tile_y * TILE);
@@ -600,7 +648,8 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
   auto gather = [&](const int k) {
     hit = false;
     if (k < n) {
-      const uint32_t id = point_list[rbase + (uint32_t)(n - 1 - k)];
+      const int pos = n - 1 - k;
+      const uint32_t id = pos < lenA ? point_list[rbase + (uint32_t)pos] : point_list[rbaseB + (uint32_t)(pos - lenA)];
       a = splats[(size_t)id * SPLAT_F4 + 0];
       b = splats[(size_t)id * SPLAT_F4 + 1];
       c = splats[(size_t)id * SPLAT_F4 + 2];
@@ -705,14 +754,53 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
   }
 }
 
+// Near/far frames: summed-area table of the tiles that still have an unfinished quad after the near phase, and their
+// number (total_live).  sat[(y + 1)(gx + 1) + (x + 1)] = live tiles in [0, x] x [0, y]; row 0 and column 0 are zero.
+// One workgroup: rows first (a thread per row), then columns (a thread per column).
+__global__ __launch_bounds__(1024) void k_live_sat(const uint8_t* __restrict__ quad_done, const int gx, const int gy,
+                                                   uint32_t* __restrict__ sat, uint32_t* __restrict__ total_live) {
+  const int sw = gx + 1;
+  for (int i = threadIdx.x; i < sw; i += 1024) sat[i] = 0u;
+  for (int y = threadIdx.x; y < gy; y += 1024) {
+    uint32_t run = 0;
+    sat[(y + 1) * sw] = 0u;
+    for (int x = 0; x < gx; x++) {
+      const uchar4 q = *reinterpret_cast<const uchar4*>(quad_done + 4 * ((size_t)y * gx + x));
+      run += (q.x & q.y & q.z & q.w) ? 0u : 1u;
+      sat[(y + 1) * sw + x + 1] = run;
+    }
+  }
+  __syncthreads();
+  for (int x = threadIdx.x; x < gx; x += 1024) {
+    uint32_t run = 0;
+    for (int y = 0; y < gy; y++) {
+      run += sat[(y + 1) * sw + x + 1];
+      sat[(y + 1) * sw + x + 1] = run;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *total_live = sat[gy * sw + gx];
+}
+
+hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, hipStream_t s) {
+  hipLaunchKernelGGL(k_live_sat, dim3(1), dim3(1024), 0, s, im.quad_done, fp.gx, fp.gy, im.live_sat, total_live);
+  return hipGetLastError();
+}
+
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
-                                float* out_color, float* out_depth, float* out_acc, hipStream_t s) {
+                                float* out_color, float* out_depth, float* out_acc, int phase, hipStream_t s) {
   ProfScope ps_k_blend_fwd(K_BLEND_FWD, s);
   // the four quads of a tile share a workgroup slot (they never synchronise): their redundant gathers of the same
   // records coincide in time and hit L1/L2; 1, 2 and 4 waves per workgroup measured within 3 % of each other
   const int quads = fp.gx * fp.gy * 4;
-  hipLaunchKernelGGL(k_blend_forward<4>, dim3((quads + 3) / 4), dim3(256), 0, s, fp, im.ranges, b.point_list, g.splats,
-                     bg, im.final_T, im.n_contrib, im.quad_last, out_color, out_depth, out_acc);
+#define GSR_LAUNCH_FWD(PH)                                                                                            \
+  hipLaunchKernelGGL((k_blend_forward<4, PH>), dim3((quads + 3) / 4), dim3(256), 0, s, fp, im.ranges, im.rangesB,      \
+                     b.point_list, g.splats, bg, im.final_T, im.n_contrib, im.quad_last, im.quad_done, out_color,      \
+                     out_depth, out_acc)
+  if (phase == 1) GSR_LAUNCH_FWD(1);
+  else if (phase == 2) GSR_LAUNCH_FWD(2);
+  else GSR_LAUNCH_FWD(0);
+#undef GSR_LAUNCH_FWD
   return hipGetLastError();
 }
 
@@ -735,12 +823,12 @@ hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningStat
     // chunks of 128 list entries (64 and 128 measured equal, 256 slower: LDS footprint)
     hipLaunchKernelGGL(k_blend_backward<128>, dim3(tiles), dim3(256), 0, s, fp, im.ranges, im.quad_last, b.point_list,
                        g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc, b.grad_inst, b.inst_flag,
-                       g.touched, order);
+                       g.touched, order, im.rangesB);
   } else {
     constexpr int TW = 4;  // (1, 2 and 4 tiles per workgroup measured equal)
     hipLaunchKernelGGL(k_blend_backward_tile<TW>, dim3((tiles + TW - 1) / TW), dim3(64 * TW), 0, s, fp, im.ranges,
                        im.quad_last, b.point_list, g.splats, g.slotinfo, bg, im.final_T, im.n_contrib, dL_dpix, dL_dacc,
-                       reinterpret_cast<float*>(b.grad_inst), b.inst_flag, g.touched, order);
+                       reinterpret_cast<float*>(b.grad_inst), b.inst_flag, g.touched, order, im.rangesB);
   }
   return hipGetLastError();
 }

@@ -65,7 +65,7 @@ typedef char* (*gsr_alloc_fn)(void* ctx, size_t bytes);
  *     the binning allocator is called a SECOND time (exact size; the first allocation may be
  *     released) and the binning chain is enqueued again; results are identical either way.
  *   gsr_last_num_rendered() returns the calling thread's last forward's exact num_rendered (the
- *   reference's return value) without touching the device.
+ *   reference's return value: the instances emitted, sorted and ranged) without touching the device.
  * The host-thread state behind this (mailbox word, counters, prediction) is per thread and device;
  * one thread's forwards must be ordered on the device (ONE stream at a time per host thread -- the
  * reference uses the default stream only); a thread that changes streams is detected and the
@@ -86,6 +86,29 @@ int gsr_last_num_rendered(void);
 long long gsr_set_binning_capacity_hint(long long capacity);
 unsigned long long gsr_speculative_forwards(void);  /* process-wide counters */
 unsigned long long gsr_speculation_overflows(void);
+
+/* Near/far frames.  A tile's list is depth-ordered and a pixel stops reading it once its transmittance
+ * is below 1e-4 (forward.cu:380-383); in dense scenes every tile is finished after a few per cent of
+ * its list, and emitting, sorting and ranging the rest is most of the forward.  A speculative forward in
+ * the default binning mode whose predicted instance count is at least four times the near budget
+ * (GSR_NEAR_ENTRIES list entries per tile, default 320) therefore bins the Gaussians in two chains
+ * in depth order: the NEAR Gaussians (until they fill the budget) are binned and blended; then only
+ * the FAR Gaussians whose tile rectangle still contains an unfinished tile are binned (whole
+ * rectangles) and blended on top.  What is left out lies, in every tile it would have gone to,
+ * behind the point where every pixel has stopped: images, n_contrib, final_T and every gradient are
+ * bit-identical to the one-chain frame; only the lists (num_rendered, point_list, ranges -- each tile's
+ * list is its near segment followed by its far segment, gsr_image_view.ranges / .ranges_far) are
+ * shorter.  Frames with gsr_set_reference_rects(1), debug frames and synchronous forwards are never
+ * split.  gsr_set_near_far(0) / GSR_NEAR_FAR=0 switches the feature off; returns the previous value.
+ * gsr_last_near_far: 1 if the calling thread's last forward was split, with its two instance counts.
+ * gsr_set_near_far_hints (test / tuning hook, calling thread): near list entries per tile (< 0 =
+ * default) and the far capacity of the NEXT split forward (< 0 = from history; too small forces the
+ * redo path). */
+int gsr_set_near_far(int on);
+int gsr_near_far(void);
+int gsr_last_near_far(unsigned* near_instances, unsigned* far_instances);
+void gsr_set_near_far_hints(long long near_entries_per_tile, long long far_capacity);
+unsigned long long gsr_near_far_forwards(void);
 
 /* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:53-88,
  * rasterizer_impl.cu:346-457).  geom/binning/image blobs are the ones the forward
@@ -133,7 +156,10 @@ typedef struct gsr_geometry_view {
                                      pipeline: filled only when the forward ran with debug != 0) */
   const uint8_t* clamped;         /* [P] bit0..2 = r,g,b clamp flags      */
   const uint32_t* depth_order;    /* [P] Gaussian ids by (depth bits, id); culled Gaussians last */
-  const uint32_t* num_rendered;   /* [1] the forward's instance count (device memory)           */
+  const uint32_t* num_rendered;   /* device counters of the forward: [0] instances of all Gaussians (= num_rendered of a
+                                     one-chain frame); near/far frames ([12] == 1): [6] near instances, [8] far
+                                     instances (num_rendered = [6] + [8]), [7] first far Gaussian in depth_order,
+                                     [9] tiles unfinished after the near phase, [10] far Gaussians emitted */
   const uint32_t* gpack;          /* [P][2]: tiles touched, packed tile rect x0 | y0 << 10 | width << 20 */
 } gsr_geometry_view;
 /* The reference's 64-bit sorted key of instance i is ((uint64)tile << 32) | bits(depths[point_list[i]]) with
@@ -145,11 +171,13 @@ typedef struct gsr_binning_view {
   const uint32_t* point_list;     /* [R] sorted Gaussian ids              */
 } gsr_binning_view;
 typedef struct gsr_image_view {
-  const uint32_t* ranges;         /* [tiles][2]                           */
+  const uint32_t* ranges;         /* [tiles][2] the tile's list segment in point_list (near segment of a near/far frame) */
   const float* final_T;           /* [H][W]                               */
   const uint32_t* n_contrib;      /* [H][W]                               */
   const uint32_t* quad_last;      /* [tiles][4] max n_contrib inside each 8x8 quad of the tile (0,1 = top, 2,3 = bottom);
                                      the tile's maximum = list entries the backward walks */
+  const uint32_t* ranges_far;     /* [tiles][2] near/far frames: the far segment that follows `ranges` in the tile's
+                                     list (positions count through both); (0, 0) otherwise */
 } gsr_image_view;
 int gsr_geometry_view_of(char* geom_buffer, int P, gsr_geometry_view* out);
 int gsr_binning_view_of(char* binning_buffer, int R, gsr_binning_view* out);

@@ -266,6 +266,89 @@ def test_internal_radii_when_the_caller_passes_none(gpu_device):
     grad_close(g[6].cpu().numpy(), ref["dL_dscales"], "dL_dscales")
 
 
+def _check_near_far_against_one_chain(sc, dev, near_entries, far_capacity=None, expect_redo=False):
+    """One scene binned in one chain (the reference's structure) and near/far: observable results bit-identical, lists
+    consistent (module docstring of include/gsraster.h, "Near/far frames")."""
+    P, W, H = sc["means3D"].shape[0], sc["W"], sc["H"]
+    G.set_binning_capacity_hint(0)
+    t0, one = hip_forward(sc, dev, debug=False)                     # synchronous, one chain
+    v1 = G.state_views(one[5], one[6], one[7], P, one[0], W, H)
+    assert not v1["near_far"]
+    assert torch.equal(v1["ranges_near"], v1["ranges"])             # one chain: the composed view is the raw one
+    dcol, dacc = S.make_upstream_grads(W, H, 5)
+    g1 = hip_backward(sc, t0, one, dcol, dacc, dev, debug=False)
+    before = G.speculation_stats()
+    G.set_near_far_hints(near_entries, far_capacity)
+    t1, two = hip_forward(sc, dev, debug=False, near_far=True)      # speculative, near/far
+    st = G.speculation_stats()
+    split, n_near, n_far = G.last_near_far()
+    assert st["overflows"] - before["overflows"] == (1 if expect_redo else 0)
+    assert split == (not expect_redo) and st["near_far_forwards"] == before["near_far_forwards"] + 1
+    for i, (x, y) in enumerate(zip(one[1:5], two[1:5])):
+        assert torch.equal(x, y), i                                 # colour, depth, silhouette, radii
+    v2 = G.state_views(two[5], two[6], two[7], P, two[0], W, H)
+    for k in ("n_contrib", "final_T", "quad_last", "tiles_touched"):
+        assert torch.equal(v1[k], v2[k]), k
+    g2 = hip_backward(sc, t1, two, dcol, dacc, dev, debug=False)
+    for k in g1:
+        assert np.array_equal(g1[k], g2[k]), k                      # every gradient, bit for bit
+    if expect_redo:
+        assert int(two[0]) == int(one[0]) and torch.equal(v1["point_list"], v2["point_list"])
+        return None
+    assert v2["near_far"] and int(two[0]) == n_near + n_far == v2["num_rendered"] <= int(one[0])
+    # lists: per tile the near/far list is the one-chain list with far entries removed only where the tile was finished
+    # by the near phase -- so its first max(n_contrib) entries, all that any pixel reads, are the same
+    r1, r2 = v1["ranges"].long().cpu().numpy(), v2["ranges"].long().cpu().numpy()
+    p1, p2 = v1["point_list"].cpu().numpy(), v2["point_list"].cpu().numpy()
+    need = v1["quad_last"].long().max(1).values.cpu().numpy()
+    rn, rf = v2["ranges_near"].long().cpu().numpy(), v2["ranges_far"].long().cpu().numpy()
+    live = ~(v2["counters"][9] == 0)
+    full_tiles = 0
+    for tidx in range(r1.shape[0]):
+        a, b = p1[r1[tidx, 0]:r1[tidx, 1]], p2[r2[tidx, 0]:r2[tidx, 1]]
+        assert len(b) <= len(a) and np.array_equal(a[:need[tidx]], b[:need[tidx]]), tidx
+        ln = rn[tidx, 1] - rn[tidx, 0]
+        assert np.array_equal(a[:ln], b[:ln])                       # the near segment is a prefix of the whole list
+        assert np.isin(b, a).all()
+        full_tiles += int(len(a) == len(b))
+    return dict(near=n_near, far=n_far, one=int(one[0]), live_tiles=v2["counters"][9], full_tiles=full_tiles,
+                tiles=r1.shape[0])
+
+
+def test_near_far_frames_equal_one_chain_frames(gpu_device):
+    """Near/far binning (gsr_set_near_far, api.hip): budgets from "far below what the pixels need" (most tiles stay
+    live: the far chain does nearly all the work) to "more than enough" (the far chain is empty), the redo path when
+    the far capacity was predicted too small, and BASELINE C3 itself with the default budget."""
+    dev = gpu_device
+    try:
+        sc = S.make_scene(40_000, 500, 300, 6, sh_degree=1)
+        for near_entries in (1, 8, 40, 200):
+            st = _check_near_far_against_one_chain(sc, dev, near_entries)
+            assert st["near"] + st["far"] <= st["one"]
+        assert st["live_tiles"] == st["tiles"]                      # (a sparse scene: no tile ever saturates)
+        # a few huge near splats over many small ones: long lists, early saturation in the image centre only
+        sc = S.make_scene(60_000, 640, 400, 16, sh_degree=0)
+        sc["means3D"][:40, 2] = 1.0
+        sc["means3D"][:40, :2] *= 0.3
+        sc["scales"][:40] = 0.29
+        sc["opacities"][:40] = 0.95
+        for near_entries in (4, 64):
+            st = _check_near_far_against_one_chain(sc, dev, near_entries)
+        assert 0 < st["live_tiles"] < st["tiles"] and st["full_tiles"] < st["tiles"]   # finished centre, live border
+        _check_near_far_against_one_chain(sc, dev, 4, far_capacity=100, expect_redo=True)   # far count > capacity
+        _check_near_far_against_one_chain(sc, dev, 4)                                        # and afterwards it works
+    finally:
+        G.set_near_far_hints(None, None)
+
+
+def test_c3_near_far(c3, gpu_device):
+    """BASELINE C3 binned near/far with the default budget (the configuration bench.py times): bit-identical images,
+    n_contrib and gradients; every tile is finished by the near phase and the far chain has nothing left to emit."""
+    sc, t, fwd = c3
+    st = _check_near_far_against_one_chain(sc, gpu_device, None)
+    assert st["live_tiles"] == 0 and st["far"] == 0 and st["near"] < st["one"] // 4
+
+
 def test_empty_input_is_a_noop(gpu_device):
     """rasterize_points.cu:92-93,183: P == 0 -> num_rendered 0, zero images, empty grads."""
     sc = S.make_scene(0, 64, 48, 1)
