@@ -207,6 +207,7 @@ struct ThreadCtx {
   long long near_entries_override = -1;
   uint32_t last_near = 0, last_far = 0;
   bool last_was_near_far = false;
+  const uint32_t* top_hist = nullptr;         // this forward's [count | tile sum] by top key byte (k_preprocess), or null
 };
 static thread_local ThreadCtx g_ctx;
 
@@ -218,8 +219,8 @@ static int ctx_prepare(ThreadCtx& c, hipStream_t stream) {
     void* d = nullptr;
     void* k = nullptr;
     if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
-        hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipMalloc(&k, 64 + 2 * 4096) != hipSuccess ||
-        hipMemset(k, 0, 64 + 2 * 4096) != hipSuccess)
+        hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipMalloc(&k, 64 + 2 * 5120) != hipSuccess ||
+        hipMemset(k, 0, 64 + 2 * 5120) != hipSuccess)
       return fail(GSR_ERR_HIP, "cannot allocate the host-mapped mailbox: %s", hipGetErrorString(hipGetLastError()));
     c.mailbox = static_cast<unsigned long long*>(h);  // (a previous device's 128 bytes stay allocated: switching is rare)
     c.mailbox_dev = static_cast<unsigned long long*>(d);
@@ -322,7 +323,8 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
                                   c.ticket, stream));
   else
     STAGE(launch_scan_offsets(fp, g, cnt, chunk_first, im.ranges, im.rangesB, b.tsort.counts, ch.near_budget,
-                              ch.phase == 1 ? c.mailbox_dev + 2 : nullptr, c.ticket, stream));
+                              ch.phase == 1 ? c.mailbox_dev + 2 : nullptr, c.ticket, ch.phase == 1 ? c.top_hist : nullptr,
+                              stream));
   STAGE(launch_emit(fp, sdesc, cnt, chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? point_list : b.ivalsB,
                     inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16,
                     /*store_pairs=*/!key16, stream));  // 16-bit keys: the pairs are generated inside the first sort pass
@@ -427,11 +429,13 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const bool own_hist_pass = env_hist_pass || !preprocess_counts_depth_digits(fp, shs, colors_precomp);
   uint32_t* const ghist2 = reinterpret_cast<uint32_t*>(reinterpret_cast<char*>(c.done_counter) + 64);
   if (!own_hist_pass) c.hist_flip ^= 1u;  // only a call that uses the pair advances it (the other buffer is clean)
-  uint32_t* const ghist_acc = own_hist_pass ? nullptr : ghist2 + 1024 * c.hist_flip;
-  uint32_t* const ghist_clear = own_hist_pass ? nullptr : ghist2 + 1024 * (c.hist_flip ^ 1u);
+  // (5 rows of 256: the four digit histograms + the tile counts summed by top byte, k_preprocess)
+  uint32_t* const ghist_acc = own_hist_pass ? nullptr : ghist2 + 1280 * c.hist_flip;
+  uint32_t* const ghist_clear = own_hist_pass ? nullptr : ghist2 + 1280 * (c.hist_flip ^ 1u);
   STAGE(launch_preprocess(fp, means3D, scales, rotations, opacities, shs, cov3D_precomp, colors_precomp, viewmatrix,
                           projmatrix, cam_pos, g, radii, /*write_cov3D=*/debug != 0, c.done_counter, c.mailbox_dev, c.ticket,
                           ghist_acc, ghist_clear, stream));
+  c.top_hist = ghist_acc ? ghist_acc + 3 * 256 : nullptr;  // rows 3 (counts by top byte) and 4 (tile sums) are adjacent
   STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, ghist_acc, stream));
   if (debug) STAGE(launch_point_offsets(fp, g, stream));  // the reference's array, for the views only
 

@@ -252,7 +252,7 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
 hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
 hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint2* ranges,
                                uint2* rangesB, uint32_t* counts0, uint32_t near_budget,
-                               unsigned long long* publish_near, uint32_t ticket, hipStream_t s);
+                               unsigned long long* publish_near, uint32_t ticket, const uint32_t* top_hist, hipStream_t s);
 hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, int capB, uint32_t slot_base, const uint32_t* sat,
                                    uint32_t* chunk_firstB, uint32_t* counts0, unsigned long long* publish,
                                    uint32_t ticket, hipStream_t s);
