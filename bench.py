@@ -392,9 +392,12 @@ def main():
         return d if all(meta.get(k) == val for k, val in this_meta.items()) else None
 
     pmc = committed("pmc_traffic_latest.json")
-    traffic = (pmc or {}).get(dom, {}).get("hbm_bytes_per_launch")
+    # device-side names behind one profiler id (the blend backward is one of two kernels, chosen by the tile count)
+    dev_names = {"k_blend_backward": ("k_blend_backward_tile", "k_blend_backward")}.get(dom, (dom,))
+    traffic = next(((pmc or {})[k].get("hbm_bytes_per_launch") for k in dev_names if k in (pmc or {})), None)
     sq = committed("sq_counters_latest.json")
-    ent = next((val for k, val in (sq or {}).items() if k.split("<")[0] == dom and isinstance(val, dict)), None)
+    ent = next((val for name in dev_names for k, val in (sq or {}).items()
+                if k.split("<")[0] == name and isinstance(val, dict)), None)
     hbm = dict(achieved=round(hbm_achieved, 1), peak=HBM_PEAK_GBS, unit="GB/s", frac=round(hbm_achieved / HBM_PEAK_GBS, 4),
                algorithmic_bytes_per_launch=int(alg[dom]))
     valu_bound = dom in ("k_blend_backward", "k_blend_forward")  # bound by VALU issue, not bytes
