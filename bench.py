@@ -340,6 +340,7 @@ def main():
         fw = G.rasterize_forward(bg, xyz, e, op, sc, rot, 1.0, e, settings.viewmatrix, settings.projmatrix,
                                  settings.tanfovx, settings.tanfovy, H, W, shs, D, settings.camera_center)
         R, radii = fw[0], fw[4]
+        nf_split, nf_near, nf_far = G.last_near_far()  # was this frame binned near / far, and the two chains' instances
         P_vis = int((radii > 0).sum())
         v = G.state_views(fw[5], fw[6], fw[7], P, R, W, H)
         ln = (v["ranges"][:, 1] - v["ranges"][:, 0]).float()
@@ -359,7 +360,8 @@ def main():
                      backward_walk_per_tile=dict(mean=float(walk.float().mean()), max=int(walk.max()),
                                                  p50=int(walk.float().quantile(0.5)), p90=int(walk.float().quantile(0.9)),
                                                  p99=int(walk.float().quantile(0.99))),
-                     binning="reference rectangles" if args.reference_rects else "footprint-culled (default)")
+                     binning="reference rectangles" if args.reference_rects else "footprint-culled (default)",
+                     near_far=dict(split=bool(nf_split), near_instances=nf_near, far_instances=nf_far))
         del fw, v
     tiles = stats["tiles"]
     alg = algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles)
