@@ -61,7 +61,8 @@ EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_byte
            "gsr_pack_ply_rows", "gsr_model_step", "gsr_set_reference_rects", "gsr_reference_rects",
            "gsr_last_num_rendered", "gsr_set_binning_capacity_hint", "gsr_speculative_forwards",
            "gsr_speculation_overflows", "gsr_mailbox_slow_path_last", "gsr_set_near_far", "gsr_near_far",
-           "gsr_last_near_far", "gsr_set_near_far_hints", "gsr_near_far_forwards")
+           "gsr_last_near_far", "gsr_set_near_far_hints", "gsr_near_far_forwards", "gsr_set_far_speculation",
+           "gsr_last_far_skipped", "gsr_far_skips", "gsr_far_skip_misses")
 
 
 def lib():
@@ -121,6 +122,13 @@ def lib():
     L.gsr_set_near_far_hints.argtypes = [C.c_longlong, C.c_longlong]
     L.gsr_near_far_forwards.restype = C.c_ulonglong
     L.gsr_near_far_forwards.argtypes = []
+    L.gsr_set_far_speculation.restype = ci
+    L.gsr_set_far_speculation.argtypes = [ci]
+    L.gsr_last_far_skipped.restype = ci
+    L.gsr_last_far_skipped.argtypes = []
+    for n in ("gsr_far_skips", "gsr_far_skip_misses"):
+        getattr(L, n).restype = C.c_ulonglong
+        getattr(L, n).argtypes = []
     L.gsr_mailbox_slow_path_last.restype = ci
     L.gsr_mailbox_slow_path_last.argtypes = [C.POINTER(MailboxEvent)]
     L.gsr_mailbox_slow_path_hits.restype = C.c_ulonglong
@@ -270,7 +278,8 @@ def set_binning_capacity_hint(capacity):
 def speculation_stats():
     L = lib()
     return dict(speculative_forwards=int(L.gsr_speculative_forwards()), overflows=int(L.gsr_speculation_overflows()),
-                near_far_forwards=int(L.gsr_near_far_forwards()),
+                near_far_forwards=int(L.gsr_near_far_forwards()), far_skips=int(L.gsr_far_skips()),
+                far_skip_misses=int(L.gsr_far_skip_misses()),
                 mailbox_slow_path_hits=int(L.gsr_mailbox_slow_path_hits()))
 
 
@@ -291,6 +300,16 @@ def set_near_far_hints(near_entries_per_tile=None, far_capacity=None):
     near/far forward (None = default / from history)."""
     lib().gsr_set_near_far_hints(-1 if near_entries_per_tile is None else int(near_entries_per_tile),
                                  -1 if far_capacity is None else int(far_capacity))
+
+
+def set_far_speculation(mode):
+    """Test / tuning hook (include/gsraster.h): True = the calling thread's next split forward does not enqueue its far
+    chain until it has seen the live-tile count, False = never, None = automatic.  Returns the previous override."""
+    return int(lib().gsr_set_far_speculation(-1 if mode is None else int(bool(mode))))
+
+
+def last_far_skipped():
+    return bool(lib().gsr_last_far_skipped())
 
 
 def last_near_far():

@@ -77,7 +77,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top", "k_sort_scatter", "k_tile_ranges", "k_blend_forward",
     "k_blend_backward", "k_compact_touched", "k_gather_records", "k_gaussian_backward", "k_mark_visible", "k_sort_hist[depth]",
     "k_sort_scan_chunks[depth]", "k_sort_scan_top[depth]", "k_sort_scatter[depth]", "k_activate",
-    "k_activate_backward", "k_adam", "k_loss_forward", "k_loss_finalize", "k_loss_backward", "k_init_gaussians", "k_pack_ply_rows", "k_model_step"};
+    "k_activate_backward", "k_adam", "k_loss_forward", "k_loss_finalize", "k_loss_backward", "k_init_gaussians", "k_pack_ply_rows", "k_model_step", "k_tile_order", "k_live_sat"};
 
 extern "C" {
 
@@ -207,6 +207,9 @@ struct ThreadCtx {
   long long near_entries_override = -1;
   uint32_t last_near = 0, last_far = 0;
   bool last_was_near_far = false;
+  int far_idle_streak = 0;                    // consecutive near/far frames of this thread that left no tile live
+  int far_skip_override = -1;                 // gsr_set_far_speculation: -1 auto, 0 never, 1 the next split forward
+  bool last_far_skipped = false;
   const uint32_t* top_hist = nullptr;         // this forward's [count | tile sum] by top key byte (k_preprocess), or null
 };
 static thread_local ThreadCtx g_ctx;
@@ -293,6 +296,29 @@ static int wait_num_rendered(ThreadCtx& c, hipStream_t stream, uint32_t* R_out, 
   }
 }
 
+// Image blobs whose backward tile order (k_tile_order) was computed by the forward that filled them: gsr_backward -- on
+// whatever host thread autograd runs it -- skips its own launch for those.  An entry exists iff the MOST RECENT forward
+// on that blob pointer computed the order: every forward drops its blob's entry on entry.
+static std::mutex g_order_mu;
+static const char* g_order_blobs[16] = {nullptr};
+static unsigned g_order_pos = 0;
+static void order_forget(const char* blob) {
+  std::lock_guard<std::mutex> lk(g_order_mu);
+  for (auto& e : g_order_blobs)
+    if (e == blob) e = nullptr;
+}
+static void order_remember(const char* blob) {
+  std::lock_guard<std::mutex> lk(g_order_mu);
+  g_order_blobs[g_order_pos++ & 15u] = blob;
+}
+static bool order_known(const char* blob) {
+  std::lock_guard<std::mutex> lk(g_order_mu);
+  for (auto& e : g_order_blobs)
+    if (e == blob) return true;
+  return false;
+}
+static std::atomic<unsigned long long> g_far_skips{0}, g_far_skip_misses{0};
+
 // One binning chain: scan -> emit -> tile sort -> ranges, followed by the blend.  A whole frame is one chain over the
 // blob (phase 0).  A near/far frame (gsr_forward) runs two chains over ONE blob carved for capA + capB instances:
 // phase 1 bins the near Gaussians into slots / list positions [0, capA), phase 2 the far Gaussians that still matter
@@ -349,7 +375,7 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
     if (bad) return fail(GSR_ERR_HIP, "%u adjacent list entries out of (depth, id) order after the sort", bad);
   }
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, ch.phase, stream));
-  if (ch.phase == 1) STAGE(launch_live_sat(fp, im, g.total + 9, stream));
+  if (ch.phase == 1) STAGE(launch_live_sat(fp, im, g.total + 9, c.mailbox_dev + 3, c.ticket, stream));
   return GSR_OK;
 }
 
@@ -404,6 +430,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   if (!iblob) return fail(GSR_ERR_ALLOC, "image allocator returned NULL");
   GeomState g = GeomState::carve(gblob, (size_t)P);
   ImageState im = ImageState::carve(iblob, width, height);
+  order_forget(iblob);
 
   // The instance count R sizes the binning blob, where the reference has its blocking cudaMemcpy
   // (rasterizer_impl.cu:277).  The last workgroup of k_preprocess stores (ticket, R) into a page-locked, host-mapped
@@ -513,16 +540,46 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       int rc = enqueue_chain(fp, g, im, b, Chain{1, Count{g.total + 6, (int)capA}, budget, 0u}, c, background, out_color,
                              out_depth, out_acc, debug, stream);
       if (rc != GSR_OK) return rc;
-      rc = enqueue_chain(fp, g, im, b, Chain{2, Count{g.total + 8, (int)capB}, 0xFFFFFFFFu, capA}, c, background,
-                         out_color, out_depth, out_acc, debug, stream);
-      if (rc != GSR_OK) return rc;
+      // Far-chain speculation.  In a dense scene the near chain finishes every tile, frame after frame, and the far
+      // chain's eleven launches find nothing to do (~60 us at 1080p).  After two such frames in a row the forward
+      // stops after the near chain: k_live_sat publishes the number of live tiles, the backward's tile order is
+      // computed here (it fills the time until the host has enqueued its next kernels), and the host reads the word.
+      // No live tile: the frame is complete -- every quad was finished by the near blend.  Otherwise (a
+      // misprediction: one host round trip) the far chain is enqueued now; the near blend has parked the unfinished
+      // pixels' state exactly as for a far chain enqueued at once, so the result is the same.
+      const bool skip_far = c.far_skip_override >= 0 ? c.far_skip_override == 1 : c.far_idle_streak >= 2;
+      if (c.far_skip_override == 1) c.far_skip_override = -1;
+      const Chain far_chain{2, Count{g.total + 8, (int)capB}, 0xFFFFFFFFu, capA};
+      uint32_t live = 0;
+      c.last_far_skipped = false;
+      if (skip_far) {
+        if ((rc = launch_tile_order(fp, im, stream)) != hipSuccess) return fail(GSR_ERR_HIP, "k_tile_order launch failed");
+      } else {
+        rc = enqueue_chain(fp, g, im, b, far_chain, c, background, out_color, out_depth, out_acc, debug, stream);
+        if (rc != GSR_OK) return rc;
+      }
       const std::chrono::steady_clock::time_point tw = std::chrono::steady_clock::now();
       if ((rc = wait_num_rendered(c, stream, &R_host)) != GSR_OK) return rc;
       if ((rc = wait_num_rendered(c, stream, &R_near, 2)) != GSR_OK) return rc;
-      if ((rc = wait_num_rendered(c, stream, &R_far, 1)) != GSR_OK) return rc;
+      if ((rc = wait_num_rendered(c, stream, &live, 3)) != GSR_OK) return rc;
+      if (skip_far && live == 0u) {
+        ++g_far_skips;
+        c.last_far_skipped = true;
+        order_remember(iblob);
+        R_far = 0;
+      } else {
+        if (skip_far) {  // live tiles after all
+          ++g_far_skip_misses;
+          rc = enqueue_chain(fp, g, im, b, far_chain, c, background, out_color, out_depth, out_acc, debug, stream);
+          if (rc != GSR_OK) return rc;
+        }
+        if ((rc = wait_num_rendered(c, stream, &R_far, 1)) != GSR_OK) return rc;
+      }
+      c.far_idle_streak = live == 0u ? c.far_idle_streak + 1 : 0;
       if (host_trace)
-        fprintf(stderr, "[gsr] near/far forward: capacity %u + %u, near %u, far %u of %u instances, enqueue %.1f us, "
-                        "then waited %.1f us\n", capA, capB, R_near, R_far, R_host,
+        fprintf(stderr, "[gsr] near/far forward: capacity %u + %u, near %u, far %u of %u instances, %u live tiles%s, "
+                        "enqueue %.1f us, then waited %.1f us\n", capA, capB, R_near, R_far, R_host, live,
+                skip_far ? (live ? " (far chain enqueued late)" : " (far chain not enqueued)") : "",
                 std::chrono::duration<double, std::micro>(tw - t_enq).count(),
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count());
       ++g_speculative_forwards;
@@ -554,6 +611,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     if (R_host > 0x7fffffffu) return fail(GSR_ERR_UNSUPPORTED, "more than 2^31 splat instances");
     if (redo) {  // misprediction: the clamped results are discarded and the frame is binned again, in one exact chain
       ++g_speculation_overflows;
+      order_forget(iblob);
       key = (int)R_host;
       // the scans run a second time: their tile tickets, look-back status words and the near-budget marker (cleared by
       // k_preprocess for the first run) must be zero again
@@ -594,6 +652,15 @@ void gsr_set_near_far_hints(long long near_entries_per_tile, long long far_capac
   if (far_capacity < 0) g_ctx.have_far = false;  // forget the far history as well
 }
 unsigned long long gsr_near_far_forwards(void) { return g_near_far_forwards.load(); }
+int gsr_set_far_speculation(int mode) {
+  const int prev = g_ctx.far_skip_override;
+  g_ctx.far_skip_override = mode < 0 ? -1 : (mode ? 1 : 0);
+  if (mode < 0) g_ctx.far_idle_streak = 0;
+  return prev;
+}
+int gsr_last_far_skipped(void) { return g_ctx.last_far_skipped ? 1 : 0; }
+unsigned long long gsr_far_skips(void) { return g_far_skips.load(); }
+unsigned long long gsr_far_skip_misses(void) { return g_far_skip_misses.load(); }
 long long gsr_set_binning_capacity_hint(long long capacity) {
   const long long prev = g_ctx.hint_override;
   g_ctx.hint_override = capacity < 0 ? -1 : (capacity > 0x7fffffffll ? 0x7fffffffll : capacity);
@@ -641,7 +708,7 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
   if (R > 0) {
     // inst_flag, touched and total[2] are zero here: the forward initialises them and the gather kernels
     // below clear what the blend backward sets, so the same blobs can be differentiated again.
-    STAGE(launch_blend_backward(fp, g, b, im, background, dL_dpix, dL_dacc, stream));
+    STAGE(launch_blend_backward(fp, g, b, im, background, dL_dpix, dL_dacc, order_known(image_buffer), stream));
     STAGE(launch_gather_records(fp, g, b, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, stream));
   }
   STAGE(launch_gaussian_backward(fp, g, b, radii, means3D, scales, rotations, colors_precomp ? nullptr : shs,

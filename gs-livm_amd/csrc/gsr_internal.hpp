@@ -285,9 +285,11 @@ hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t
 hipError_t launch_tile_ranges(const uint32_t* tile_ids, Count R, uint2* ranges, bool key16, uint32_t list_base, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, int phase, hipStream_t s);
-hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, hipStream_t s);
+hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, unsigned long long* publish,
+                           uint32_t ticket, hipStream_t s);
+hipError_t launch_tile_order(const FrameParams& fp, ImageState im, hipStream_t s);
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
-                                 const float* dL_dpix, const float* dL_dacc, hipStream_t s);
+                                 const float* dL_dpix, const float* dL_dacc, bool have_tile_order, hipStream_t s);
 hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningState b, const int* radii,
                                     const float* means3D, const float* scales, const float* rotations,
                                     const float* shs, const float* cov3D_precomp, const float* view, const float* proj,
@@ -331,7 +333,7 @@ enum KernelId {
   K_PREPROCESS = 0, K_POINT_OFFSETS, K_SCAN_OFFSETS, K_EMIT, K_SORT_HIST,
   K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_COMPACT_TOUCHED,
   K_GATHER_RECORDS, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_DSORT_HIST, K_DSORT_SCAN_CHUNKS, K_DSORT_SCAN_TOP,
-  K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_LOSS_FWD, K_LOSS_FINALIZE, K_LOSS_BWD, K_INIT_GAUSSIANS, K_PACK_PLY, K_MODEL_STEP, K_COUNT
+  K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_LOSS_FWD, K_LOSS_FINALIZE, K_LOSS_BWD, K_INIT_GAUSSIANS, K_PACK_PLY, K_MODEL_STEP, K_TILE_ORDER, K_LIVE_SAT, K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);

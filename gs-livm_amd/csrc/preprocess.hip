@@ -523,7 +523,11 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
   // comes from total[0].
   const uint32_t R_total = split ? g.total[0] : (uint32_t)cnt.get();
   const int R = (int)R_total;
-  if (blockIdx.x == 0 && tid == 0) g.total[12] = split ? 1u : 0u;  // marks the frame for the views (api.hip)
+  if (blockIdx.x == 0 && tid == 0) {
+    g.total[12] = split ? 1u : 0u;  // marks the frame for the views (api.hip)
+    g.total[8] = 0u;                // far-phase totals: a frame whose far chain is never enqueued has none
+    g.total[10] = 0u;
+  }
   // side job: (0, 0) for the tiles no instance lands in
   for (int t = blockIdx.x * PRE_BLOCK + tid; t < fp.gx * fp.gy; t += gridDim.x * PRE_BLOCK) {
     ranges[t] = make_uint2(0u, 0u);

@@ -761,7 +761,8 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
 // the global-memory variant below walks rows and columns with dependent loads: 54 us).
 template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void k_live_sat(const uint8_t* __restrict__ quad_done, const int gx, const int gy,
-                                                   uint32_t* __restrict__ sat, uint32_t* __restrict__ total_live) {
+                                                   uint32_t* __restrict__ sat, uint32_t* __restrict__ total_live,
+                                                   unsigned long long* __restrict__ publish, const uint32_t ticket) {
   extern __shared__ uint32_t s_sat[];
   uint32_t* const S = IN_LDS ? s_sat : sat;
   const int sw = gx + 1, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -814,19 +815,28 @@ __global__ __launch_bounds__(1024) void k_live_sat(const uint8_t* __restrict__ q
   __syncthreads();
   if (IN_LDS)
     for (int i = tid; i < sw * (gy + 1); i += 1024) sat[i] = S[i];
-  if (tid == 0) *total_live = S[gy * sw + gx];
+  if (tid == 0) {
+    const uint32_t live = S[gy * sw + gx];
+    *total_live = live;
+    // the host's copy (api.hip: a frame whose far chain was not enqueued is complete iff no tile is live)
+    if (publish)
+      __hip_atomic_store(publish, ((unsigned long long)ticket << 32) | live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
-hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, hipStream_t s) {
+hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, unsigned long long* publish,
+                           uint32_t ticket, hipStream_t s) {
+  ProfScope ps(K_LIVE_SAT, s);
   const size_t bytes = (size_t)(fp.gx + 1) * (fp.gy + 1) * sizeof(uint32_t);
   if (bytes <= 150 * 1024) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_live_sat<true>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(k_live_sat<true>, dim3(1), dim3(1024), bytes, s, im.quad_done, fp.gx, fp.gy, im.live_sat,
-                       total_live);
+                       total_live, publish, ticket);
   } else {
-    hipLaunchKernelGGL(k_live_sat<false>, dim3(1), dim3(1024), 0, s, im.quad_done, fp.gx, fp.gy, im.live_sat, total_live);
+    hipLaunchKernelGGL(k_live_sat<false>, dim3(1), dim3(1024), 0, s, im.quad_done, fp.gx, fp.gy, im.live_sat, total_live,
+                       publish, ticket);
   }
   return hipGetLastError();
 }
@@ -848,8 +858,25 @@ hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState
   return hipGetLastError();
 }
 
+// Tile order of the backward (k_tile_order) as a launch of its own: a forward that has nothing else left to enqueue
+// computes it at its end (api.hip), where it fills the gap until the host has enqueued the next kernels.
+static bool backward_image_order() {
+  static const bool image_order = getenv("GSR_BWD_IMAGE_ORDER") != nullptr;  // experiment knob
+  return image_order;
+}
+hipError_t launch_tile_order(const FrameParams& fp, ImageState im, hipStream_t s) {
+  if (backward_image_order()) return hipSuccess;
+  ProfScope ps(K_TILE_ORDER, s);
+  hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.quad_last, fp.gx * fp.gy, im.tile_order);
+  return hipGetLastError();
+}
+
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
-                                 const float* dL_dpix, const float* dL_dacc, hipStream_t s) {
+                                 const float* dL_dpix, const float* dL_dacc, bool have_tile_order, hipStream_t s) {
+  if (!have_tile_order) {
+    const hipError_t e = launch_tile_order(fp, im, s);
+    if (e != hipSuccess) return e;
+  }
   ProfScope ps_k_blend_bwd(K_BLEND_BWD, s);
   // Two kernels, chosen by the number of tiles.  One wave per tile (four pixels per lane, one reduction per 256
   // pixels) needs a frame with at least ~3000 tiles to fill the chip -- a tile is one wave's serial job -- and then wins
@@ -858,11 +885,9 @@ hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningStat
   // first.  GSR_BLEND_BACKWARD_QUADS=1 / GSR_BLEND_BACKWARD_TILES=1 force one of them (diagnostics, tests).
   static const bool force_quad = getenv("GSR_BLEND_BACKWARD_QUADS") != nullptr;
   static const bool force_tile = getenv("GSR_BLEND_BACKWARD_TILES") != nullptr;
-  static const bool image_order = getenv("GSR_BWD_IMAGE_ORDER") != nullptr;  // experiment knob
   const int tiles = fp.gx * fp.gy;
   const bool per_quad = force_quad || (!force_tile && tiles < 3072);
-  const uint32_t* order = image_order ? nullptr : im.tile_order;
-  if (order) hipLaunchKernelGGL(k_tile_order, dim3(1), dim3(1024), 0, s, im.quad_last, tiles, im.tile_order);
+  const uint32_t* order = backward_image_order() ? nullptr : im.tile_order;
   if (per_quad) {
     // chunks of 128 list entries (64 and 128 measured equal, 256 slower: LDS footprint)
     hipLaunchKernelGGL(k_blend_backward<128>, dim3(tiles), dim3(256), 0, s, fp, im.ranges, im.quad_last, b.point_list,

@@ -109,6 +109,18 @@ int gsr_near_far(void);
 int gsr_last_near_far(unsigned* near_instances, unsigned* far_instances);
 void gsr_set_near_far_hints(long long near_entries_per_tile, long long far_capacity);
 unsigned long long gsr_near_far_forwards(void);
+/* Far-chain speculation.  When a thread's last two split forwards left no tile live after the near chain
+ * (a dense scene: the far chain's launches found nothing to do), its next split forward does not enqueue
+ * the far chain: the near chain ends with the count of live tiles in the mailbox and the backward's tile
+ * order, and the host reads that word where it reads num_rendered.  Zero: the frame is complete.
+ * Otherwise the far chain is enqueued then (one host round trip); results are identical either way.
+ * gsr_set_far_speculation (test / tuning hook, calling thread): 1 = the NEXT split forward speculates,
+ * 0 = none does, negative = automatic (and the streak restarts); returns the previous setting.
+ * gsr_last_far_skipped: 1 if the calling thread's last forward completed without a far chain. */
+int gsr_set_far_speculation(int mode);
+int gsr_last_far_skipped(void);
+unsigned long long gsr_far_skips(void);       /* process-wide counters */
+unsigned long long gsr_far_skip_misses(void);
 
 /* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:53-88,
  * rasterizer_impl.cu:346-457).  geom/binning/image blobs are the ones the forward

@@ -46,7 +46,7 @@ def hip_backward(scene, t, fwd, dL_dcolor, dL_dacc, dev, debug=True):
     return {n: x.cpu().numpy() for n, x in zip(names, g)}
 
 
-def grad_close(got, ref, name, cond=None):
+def grad_close(got, ref, name, cond=None, outlier_frac=0.0):
     """SURVEY.md Appendix B tolerance, |d| <= 1e-5 * max|g| + 1e-4 * |g|, with |g| taken as the largest
     component of the SAME Gaussian's gradient group (row): the f32 summation order differs from the
     oracle's, and the conic -> cov2D -> cov3D chain cancels large terms, so one component of a group can
@@ -57,7 +57,12 @@ def grad_close(got, ref, name, cond=None):
     whose terms cancel, and the backward inverts that matrix (backward.cu:140-275).  The oracle itself moves by
     more than the plain bound on such rows when only its summation order changes (tools/debug_random_scenes.py).
     With cond given, a row's bound is widened by (1 + cond / 10); 99.9 % of the elements must meet the widened
-    bound and none may exceed it 20-fold."""
+    bound and none may exceed it 20-fold.
+
+    outlier_frac (full-size runs against the MULTI-THREADED oracle only): that oracle accumulates with f32 `omp atomic`
+    adds in arbitrary order, as the reference's atomicAdd does, so its own result moves in the last bits from run to
+    run; among 10^7 elements a handful then sit a hair outside the bound in some runs (observed: 1 of 12 M, 1.7e-6
+    against a bound of 1.3e-6).  Up to this fraction may exceed the bound, none by more than 4x."""
     ref = ref.reshape(got.shape)
     if ref.size == 0:
         return
@@ -74,6 +79,8 @@ def grad_close(got, ref, name, cond=None):
         name, int(bad.sum()), bad.size, float(err.max()), scale)
     if cond is not None:
         assert bad.mean() <= 1e-3 and not (err > 20.0 * tol).any(), msg
+    elif outlier_frac > 0.0:
+        assert bad.mean() <= outlier_frac and not (err > 4.0 * tol).any(), msg
     else:
         assert not bad.any(), msg
 

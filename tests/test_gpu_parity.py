@@ -266,7 +266,7 @@ def test_internal_radii_when_the_caller_passes_none(gpu_device):
     grad_close(g[6].cpu().numpy(), ref["dL_dscales"], "dL_dscales")
 
 
-def _check_near_far_against_one_chain(sc, dev, near_entries, far_capacity=None, expect_redo=False):
+def _check_near_far_against_one_chain(sc, dev, near_entries, far_capacity=None, expect_redo=False, speculate_far=None):
     """One scene binned in one chain (the reference's structure) and near/far: observable results bit-identical, lists
     consistent (module docstring of include/gsraster.h, "Near/far frames")."""
     P, W, H = sc["means3D"].shape[0], sc["W"], sc["H"]
@@ -279,8 +279,11 @@ def _check_near_far_against_one_chain(sc, dev, near_entries, far_capacity=None, 
     g1 = hip_backward(sc, t0, one, dcol, dacc, dev, debug=False)
     before = G.speculation_stats()
     G.set_near_far_hints(near_entries, far_capacity)
+    if speculate_far is not None:   # True: this forward enqueues its far chain only once it has seen live tiles
+        G.set_far_speculation(speculate_far)
     t1, two = hip_forward(sc, dev, debug=False, near_far=True)      # speculative, near/far
     st = G.speculation_stats()
+    far_skipped = G.last_far_skipped()
     split, n_near, n_far = G.last_near_far()
     assert st["overflows"] - before["overflows"] == (1 if expect_redo else 0)
     assert split == (not expect_redo) and st["near_far_forwards"] == before["near_far_forwards"] + 1
@@ -311,8 +314,14 @@ def _check_near_far_against_one_chain(sc, dev, near_entries, far_capacity=None, 
         assert np.array_equal(a[:ln], b[:ln])                       # the near segment is a prefix of the whole list
         assert np.isin(b, a).all()
         full_tiles += int(len(a) == len(b))
+    if speculate_far:   # completed without a far chain iff the near chain left no tile live
+        assert far_skipped == (v2["counters"][9] == 0)
+        assert st["far_skips"] - before["far_skips"] == int(far_skipped)
+        assert st["far_skip_misses"] - before["far_skip_misses"] == int(not far_skipped)
+    elif speculate_far is False:
+        assert not far_skipped and st["far_skips"] == before["far_skips"]
     return dict(near=n_near, far=n_far, one=int(one[0]), live_tiles=v2["counters"][9], full_tiles=full_tiles,
-                tiles=r1.shape[0])
+                tiles=r1.shape[0], far_skipped=far_skipped)
 
 
 def test_near_far_frames_equal_one_chain_frames(gpu_device):
@@ -337,8 +346,27 @@ def test_near_far_frames_equal_one_chain_frames(gpu_device):
         assert 0 < st["live_tiles"] < st["tiles"] and st["full_tiles"] < st["tiles"]   # finished centre, live border
         _check_near_far_against_one_chain(sc, dev, 4, far_capacity=100, expect_redo=True)   # far count > capacity
         _check_near_far_against_one_chain(sc, dev, 4)                                        # and afterwards it works
+        # far-chain speculation (gsr_set_far_speculation) that turns out wrong: tiles stay live, the far chain is
+        # enqueued after the host has seen the count -- same frame, and the backward sorts its tiles itself
+        st = _check_near_far_against_one_chain(sc, dev, 4, speculate_far=True)
+        assert st["live_tiles"] > 0 and st["far"] > 0 and not st["far_skipped"]
+        _check_near_far_against_one_chain(sc, dev, 4, speculate_far=True, far_capacity=100, expect_redo=True)
+        # ... and right: a stack of opaque screen-filling splats in front finishes every tile within the near budget
+        sc = S.make_scene(30_000, 320, 208, 23, sh_degree=0)
+        sc["means3D"][:64, :2] = 0.0
+        sc["means3D"][:64, 2] = np.linspace(0.5, 0.9, 64, dtype=np.float32)
+        sc["scales"][:64] = 0.29
+        sc["opacities"][:64] = 0.98
+        st = _check_near_far_against_one_chain(sc, dev, 200, speculate_far=True)
+        assert st["live_tiles"] == 0 and st["far"] == 0 and st["far_skipped"]
+        # automatic: after two split frames without a live tile the third one speculates
+        G.set_far_speculation(None)
+        for k in range(3):
+            st = _check_near_far_against_one_chain(sc, dev, 200)
+            assert st["far_skipped"] == (k == 2), k
     finally:
         G.set_near_far_hints(None, None)
+        G.set_far_speculation(None)
 
 
 def test_c3_near_far(c3, gpu_device):
@@ -347,6 +375,11 @@ def test_c3_near_far(c3, gpu_device):
     sc, t, fwd = c3
     st = _check_near_far_against_one_chain(sc, gpu_device, None)
     assert st["live_tiles"] == 0 and st["far"] == 0 and st["near"] < st["one"] // 4
+    try:  # and without a far chain at all (far-chain speculation, the steady state of bench.py)
+        st = _check_near_far_against_one_chain(sc, gpu_device, None, speculate_far=True)
+        assert st["far_skipped"] and st["far"] == 0
+    finally:
+        G.set_far_speculation(None)
 
 
 def test_empty_input_is_a_noop(gpu_device):
@@ -824,8 +857,8 @@ def test_c3_full_parity_with_oracle(c3, gpu_device):
     dcol, dacc = masked_grads(W, H, seed, fr.fragile)
     ref = O.backward(fr, sc, dcol, dacc)
     got = hip_backward(sc, t, fwd, dcol, dacc, gpu_device, debug=False)
-    for k in GRAD_NAMES:
-        grad_close(got[k], ref[k], k)
+    for k in GRAD_NAMES:   # (16-thread oracle: atomic-order noise of its own, see grad_close)
+        grad_close(got[k], ref[k], k, outlier_frac=1e-6)
     R_ref = fr.R
     fr.close()
     del fr, fwd
@@ -834,7 +867,7 @@ def test_c3_full_parity_with_oracle(c3, gpu_device):
     check_forward(sc, ft, fwd_c, gpu_device, debug=False)
     got_c = hip_backward(sc, t_c, fwd_c, dcol, dacc, gpu_device, debug=False)
     for k in GRAD_NAMES:                                 # same gradients from the shorter lists
-        grad_close(got_c[k], ref[k], k)
+        grad_close(got_c[k], ref[k], k, outlier_frac=1e-6)
 
 
 def test_c4_eight_views_forward_parity(gpu_device):
