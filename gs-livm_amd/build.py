@@ -20,7 +20,7 @@ HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 COMMON = ["--offload-arch=" + ARCH, "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
-          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC]
+          "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + os.environ.get("GSR_EXTRA_FLAGS", "").split()
 # translation unit -> extra flags.  preprocess.hip feeds the exact-match integer outputs and must
 # not be contracted into FMAs (see its header); the blend kernels are tolerance-checked and may.
 UNITS = {

@@ -344,9 +344,11 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
   uint32_t* point_list = b.point_list + ch.base;
   uint8_t* inst_flag = b.inst_flag + ch.base;
   uint2* ranges = far ? im.rangesB : im.ranges;
-  if (far)
+  if (far) {
+    STAGE(launch_live_sat(fp, im, g.total + 9, stream));  // which tiles did the near chain leave unfinished
     STAGE(launch_scan_offsets_far(fp, g, cnt.cap, ch.base, im.live_sat, chunk_first, b.tsort.counts, c.mailbox_dev + 1,
                                   c.ticket, stream));
+  }
   else
     STAGE(launch_scan_offsets(fp, g, cnt, chunk_first, im.ranges, im.rangesB, b.tsort.counts, ch.near_budget,
                               ch.phase == 1 ? c.mailbox_dev + 2 : nullptr, c.ticket, ch.phase == 1 ? c.top_hist : nullptr,
@@ -374,8 +376,9 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
     HIP_TRY(hipStreamSynchronize(stream));
     if (bad) return fail(GSR_ERR_HIP, "%u adjacent list entries out of (depth, id) order after the sort", bad);
   }
-  STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, ch.phase, stream));
-  if (ch.phase == 1) STAGE(launch_live_sat(fp, im, g.total + 9, c.mailbox_dev + 3, c.ticket, stream));
+  // (the near blend counts the quads it leaves unfinished into the host's mailbox: done word 1, mailbox word 3)
+  STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, ch.phase, c.done_counter + 1,
+                             c.mailbox_dev + 3, c.ticket, stream));
   return GSR_OK;
 }
 
@@ -542,7 +545,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       if (rc != GSR_OK) return rc;
       // Far-chain speculation.  In a dense scene the near chain finishes every tile, frame after frame, and the far
       // chain's eleven launches find nothing to do (~60 us at 1080p).  After two such frames in a row the forward
-      // stops after the near chain: k_live_sat publishes the number of live tiles, the backward's tile order is
+      // stops after the near chain: the near blend's last workgroup publishes the number of unfinished quads, the backward's tile order is
       // computed here (it fills the time until the host has enqueued its next kernels), and the host reads the word.
       // No live tile: the frame is complete -- every quad was finished by the near blend.  Otherwise (a
       // misprediction: one host round trip) the far chain is enqueued now; the near blend has parked the unfinished
@@ -577,7 +580,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       }
       c.far_idle_streak = live == 0u ? c.far_idle_streak + 1 : 0;
       if (host_trace)
-        fprintf(stderr, "[gsr] near/far forward: capacity %u + %u, near %u, far %u of %u instances, %u live tiles%s, "
+        fprintf(stderr, "[gsr] near/far forward: capacity %u + %u, near %u, far %u of %u instances, %u unfinished quads%s, "
                         "enqueue %.1f us, then waited %.1f us\n", capA, capB, R_near, R_far, R_host, live,
                 skip_far ? (live ? " (far chain enqueued late)" : " (far chain not enqueued)") : "",
                 std::chrono::duration<double, std::micro>(tw - t_enq).count(),

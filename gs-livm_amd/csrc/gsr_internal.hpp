@@ -111,7 +111,7 @@ struct GeomState {
                             // [6] instances of the near phase, [7] depth-order index of the first far Gaussian,
                             // [8] instances of the far phase, [9] tiles still live after the near phase, [10] far
                             // Gaussians emitted, [11] scan tile in which the near budget was crossed (+1; 0 = not yet),
-                            // [12] 1 = this frame was binned near/far
+                            // [12] 1 = this frame was binned near/far, [13] quads the near blend left unfinished
   uint2* slotinfo;          // {first slot of the Gaussian's instance run, x0 | y0 << 10 | rect_width << 20}
   uint2* gpack;             // {tiles_touched, packed rect} per Gaussian: ONE 8-byte gather in depth order (the only
                             // copy of the tile counts)
@@ -284,9 +284,10 @@ hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t
                                       uint32_t* violations, hipStream_t s);
 hipError_t launch_tile_ranges(const uint32_t* tile_ids, Count R, uint2* ranges, bool key16, uint32_t list_base, hipStream_t s);
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
-                                float* out_color, float* out_depth, float* out_acc, int phase, hipStream_t s);
-hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, unsigned long long* publish,
-                           uint32_t ticket, hipStream_t s);
+                                float* out_color, float* out_depth, float* out_acc, int phase,
+                                unsigned long long* done_word, unsigned long long* publish, uint32_t ticket,
+                                hipStream_t s);
+hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, hipStream_t s);
 hipError_t launch_tile_order(const FrameParams& fp, ImageState im, hipStream_t s);
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                  const float* dL_dpix, const float* dL_dacc, bool have_tile_order, hipStream_t s);

@@ -192,7 +192,15 @@ static inline size_t sh_stage_bytes(int M) {
 // ------------------------------------------------------------------------------------------------
 // F1.  One thread per Gaussian.  Replaces preprocessCUDA (reference forward.cu:179-286).
 // ------------------------------------------------------------------------------------------------
-template <bool STAGED>
+// PLAIN = the product's configuration, fixed at compile time: SH degree 0 read from `shs`, scales + rotations given, no
+// precomputed covariance or colour.  The general variant keeps those inputs behind run-time branches, and every such
+// branch with a load in it ends in an `s_waitcnt vmcnt(0)` at the join -- vector loads return in order, so that wait
+// also waits for the NEXT block's inputs requested at the top of the iteration, and the prefetch never overlaps the
+// arithmetic.  With the branches compiled away no load is issued between the prefetch and the next iteration.
+#ifndef GSR_PRE_VARIANT
+#define GSR_PRE_VARIANT 0
+#endif
+template <bool STAGED, bool PLAIN = false>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     const FrameParams fp, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
@@ -205,6 +213,16 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   // workgroup b walks the 256-Gaussian blocks b, b + grid, b + 2 grid, ...: no second, mostly empty round of
   // workgroups at the end, every workgroup does the same number of blocks (+-1), and the instance count below
   // costs one same-address atomic per workgroup (they retire one at a time, ~5 ns each) instead of one per block.
+  // The two camera matrices are read ONCE, here, before the first store of the kernel: uniform addresses that nothing
+  // has clobbered yet become scalar loads into SGPRs.  Read where they are used -- inside the block loop, behind the
+  // previous block's stores -- the compiler had to fetch every entry with a vector load per thread (25 per Gaussian), and
+  // since vector loads return in order, waiting for one of them also waited for the NEXT block's inputs requested
+  // just before: the prefetch never overlapped the arithmetic.
+  if (blockIdx.x == 0 && threadIdx.x == 0) { g.total[2] = 0u; g.total[11] = 0u; }  // ([11]: no near budget crossed yet)
+  float Vc[16], Pc[16];
+#pragma unroll
+  for (int k = 0; k < 16; k++) { Vc[k] = V[k]; Pc[k] = Pm[k]; }
+  const float cam0 = campos[0], cam1 = campos[1], cam2 = campos[2];
   extern __shared__ float sh_rows[];  // STAGED: the sub-block's SH rows (rows_to_lds)
   // The depth sort's four digit histograms are counted here, where the keys are made (LDS atomics, one flush of
   // the non-empty bins per workgroup): the sort needs no histogram pass of its own.  ghist_acc is library-owned
@@ -214,6 +232,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   // (row 4: the tile counts summed by the keys' TOP byte -- with row 3 it tells k_scan_offsets how far into the depth
   // order the near phase of a near/far frame can reach)
   __shared__ uint32_t dhist[STAGED ? 1 : 5][STAGED ? 1 : 256];
+  __shared__ float4 s_rec[PRE_BLOCK / 64][64 * SPLAT_F4];  // per wave: the records of its 64 Gaussians on their way out
   if (!STAGED && ghist_acc) {
 #pragma unroll
     for (int k = 0; k < 5; k++) dhist[k][threadIdx.x] = 0u;
@@ -226,30 +245,37 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   // stage: means -> scales -> rotation -> opacity / colour), and the NEXT sub-block's inputs are requested before
   // this one is worked on, so the arithmetic of a wave overlaps its own loads.
   struct In { float mx, my, mz, s0, s1, s2, op, dc0, dc1, dc2; float4 q; };
-  const bool dc_direct = !STAGED && shs && !colors_precomp;  // first SH coefficient read with the other inputs
-  auto fetch = [&](const int i) {
+  const bool dc_direct = PLAIN || (!STAGED && shs && !colors_precomp);  // first SH coefficient read with the other inputs
+  const int D = PLAIN ? 0 : fp.D;
+  // (always executed, on an index clamped into the array: a load behind a branch is merged with the "not loaded" value
+  // by a register copy placed right after it, and that copy makes the wave wait for the load at once)
+  auto fetch = [&](const int i_) {
     In v;
-    v.mx = v.my = v.mz = v.s0 = v.s1 = v.s2 = v.op = v.dc0 = v.dc1 = v.dc2 = 0.f;
+    const int i = i_ < fp.P ? i_ : fp.P - 1;
+    v.s0 = v.s1 = v.s2 = v.dc0 = v.dc1 = v.dc2 = 0.f;
     v.q = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < fp.P) {
-      v.mx = means3D[3 * i]; v.my = means3D[3 * i + 1]; v.mz = means3D[3 * i + 2];
-      if (scales) { v.s0 = scales[3 * i]; v.s1 = scales[3 * i + 1]; v.s2 = scales[3 * i + 2]; }
-      if (!cov3D_precomp) v.q = reinterpret_cast<const float4*>(rotations)[i];
-      v.op = opacities[i];
-      if (dc_direct) {
-        const float* r = shs + (size_t)i * fp.M * 3;
-        v.dc0 = r[0]; v.dc1 = r[1]; v.dc2 = r[2];
-      }
+    v.mx = means3D[3 * i]; v.my = means3D[3 * i + 1]; v.mz = means3D[3 * i + 2];
+    if (PLAIN || scales) { v.s0 = scales[3 * i]; v.s1 = scales[3 * i + 1]; v.s2 = scales[3 * i + 2]; }
+    if (PLAIN || !cov3D_precomp) v.q = reinterpret_cast<const float4*>(rotations)[i];
+    v.op = opacities[i];
+    if (dc_direct) {
+      const float* r = shs + (size_t)i * fp.M * 3;
+      v.dc0 = r[0]; v.dc1 = r[1]; v.dc2 = r[2];
     }
     return v;
   };
   uint32_t tiles_wg = 0;
   const int nblk = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
-  In nxt = fetch(blockIdx.x * PRE_BLOCK + threadIdx.x);
-  for (int blk = blockIdx.x; blk < nblk; blk += gridDim.x) {
-  const int idx = blk * PRE_BLOCK + threadIdx.x;
-  const In in = nxt;
-  if (blk + (int)gridDim.x < nblk) nxt = fetch(idx + (int)gridDim.x * PRE_BLOCK);
+  // one block of 256 Gaussians whose inputs are in registers
+  // Every vector-memory instruction of a block is issued UNCONDITIONALLY: the hardware counts loads and stores in one
+  // in-order counter, and as soon as a store sits behind a branch the compiler no longer knows how many are in flight
+  // and waits for ALL of them (vmcnt(0)) wherever it needs an earlier load -- i.e. for the stores it has just issued,
+  // every block.  So the lanes of the last block that lie beyond P act as duplicates of Gaussian P - 1 (fetch() clamps
+  // the same way): same inputs, same results, stored to the same place (a benign same-value race), not counted.
+  auto work = [&](const In& in, const int blk, auto&& before_stores) {
+  const int idx_raw = blk * PRE_BLOCK + threadIdx.x;
+  const bool dup = idx_raw >= fp.P;
+  const int idx = dup ? fp.P - 1 : idx_raw;
   if (STAGED) {
     const int row0 = blk * PRE_BLOCK;
     if (blk != (int)blockIdx.x) __syncthreads();  // the previous block's rows have been read
@@ -258,25 +284,28 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   }
   uint32_t tiles = 0, rect_packed = 0, dkey = 0xFFFFFFFFu;
   int radius = 0;
-  if (idx < fp.P) {
+  float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0;  // splat record (zeros for a culled Gaussian)
+  bool tiles_any = false; (void)tiles_any;
+  uint8_t clamp_out = 0;
+  {
     const float mx = in.mx, my = in.my, mz = in.mz;
-    const float pvz = V[2] * mx + V[6] * my + V[10] * mz + V[14];
+    const float pvz = Vc[2] * mx + Vc[6] * my + Vc[10] * mz + Vc[14];
     bool alive = !(pvz <= 0.2f);  // near cull only (forward.cu:221-225)
     float s0 = 0, s1 = 0, s2 = 0;
-    if (alive && scales) {  // scale cull (forward.cu:19-25)
+    if (alive && (PLAIN || scales)) {  // scale cull (forward.cu:19-25)
       s0 = fp.scale_modifier * in.s0;
       s1 = fp.scale_modifier * in.s1;
       s2 = fp.scale_modifier * in.s2;
       alive = !(s0 > 0.3f || s1 > 0.3f || s2 > 0.3f);
     }
     if (alive) {
-      const float ph0 = Pm[0] * mx + Pm[4] * my + Pm[8] * mz + Pm[12];
-      const float ph1 = Pm[1] * mx + Pm[5] * my + Pm[9] * mz + Pm[13];
-      const float ph3 = Pm[3] * mx + Pm[7] * my + Pm[11] * mz + Pm[15];
+      const float ph0 = Pc[0] * mx + Pc[4] * my + Pc[8] * mz + Pc[12];
+      const float ph1 = Pc[1] * mx + Pc[5] * my + Pc[9] * mz + Pc[13];
+      const float ph3 = Pc[3] * mx + Pc[7] * my + Pc[11] * mz + Pc[15];
       const float pw = 1.0f / (ph3 + 0.0000001f);
       const float ppx = ph0 * pw, ppy = ph1 * pw;
       float c6[6];
-      if (cov3D_precomp) {
+      if (!PLAIN && cov3D_precomp) {
 #pragma unroll
         for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * idx + k];
       } else {
@@ -286,7 +315,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
           for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)idx + k] = c6[k];
         }
       }
-      const Ewa e = ewa_project(mx, my, mz, fp, c6, V);
+      const Ewa e = ewa_project(mx, my, mz, fp, c6, Vc);
       const float cx = e.cxx + 0.3f, cy = e.cxy, cz = e.cyy + 0.3f;
       const float det = cx * cz - cy * cy;
       if (det != 0.0f) {
@@ -303,30 +332,32 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
         if (area != 0) {
           float rgb[3];
           uint8_t clampbits = 0;
-          if (colors_precomp) {
+          if (!PLAIN && colors_precomp) {
             rgb[0] = colors_precomp[3 * idx];
             rgb[1] = colors_precomp[3 * idx + 1];
             rgb[2] = colors_precomp[3 * idx + 2];
           } else {  // SH -> RGB (forward.cu:29-76)
             float x = 0.f, y = 0.f, z = 0.f;
-            if (fp.D > 0) {  // the view direction only enters from degree 1 on (the product runs degree 0)
-              const float d0 = mx - campos[0], d1 = my - campos[1], d2 = mz - campos[2];
+            if (D > 0) {  // the view direction only enters from degree 1 on (the product runs degree 0)
+              const float d0 = mx - cam0, d1 = my - cam1, d2 = mz - cam2;
               const float len = sqrtf(d0 * d0 + d1 * d1 + d2 * d2);
               x = d0 / len; y = d1 / len; z = d2 / len;
             }
-            const float* sh = STAGED ? sh_rows + threadIdx.x * sh_row_stride(fp.M * 3) : shs + (size_t)idx * fp.M * 3;
+            // (STAGED: the block's rows sit in LDS in block order; a duplicate lane reads Gaussian P - 1's row)
+            const float* sh = STAGED ? sh_rows + (idx - blk * PRE_BLOCK) * sh_row_stride(fp.M * 3)
+                                     : shs + (size_t)idx * fp.M * 3;
             const float dc[3] = {dc_direct ? in.dc0 : sh[0], dc_direct ? in.dc1 : sh[1], dc_direct ? in.dc2 : sh[2]};
 #pragma unroll
             for (int ch = 0; ch < 3; ch++) {
               float res = SH0 * dc[ch];
-              if (fp.D > 0) {
+              if (D > 0) {
                 res = res - SH1 * y * sh[3 + ch] + SH1 * z * sh[6 + ch] - SH1 * x * sh[9 + ch];
-                if (fp.D > 1) {
+                if (D > 1) {
                   const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
                   res = res + SH2c[0] * xy * sh[12 + ch] + SH2c[1] * yz * sh[15 + ch] +
                         SH2c[2] * (2.0f * zz - xx - yy) * sh[18 + ch] + SH2c[3] * xz * sh[21 + ch] +
                         SH2c[4] * (xx - yy) * sh[24 + ch];
-                  if (fp.D > 2) {
+                  if (D > 2) {
                     res = res + SH3c[0] * y * (3.0f * xx - yy) * sh[27 + ch] + SH3c[1] * xy * z * sh[30 + ch] +
                           SH3c[2] * y * (4.0f * zz - xx - yy) * sh[33 + ch] +
                           SH3c[3] * z * (2.0f * zz - 3.0f * xx - 3.0f * yy) * sh[36 + ch] +
@@ -381,25 +412,63 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
           tiles = (x1 > x0 && y1 > y0) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
           rect_packed = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
           if (tiles) dkey = __float_as_uint(pvz);  // depth > 0.2: the bit pattern orders like the value
-          float4* rec = g.splats + (size_t)idx * SPLAT_F4;
-          rec[0] = make_float4(pixx, pixy, conx, cony);
-          rec[1] = make_float4(conz, op, rgb[0], rgb[1]);
-          rec[2] = make_float4(rgb[2], pvz, hx, hy);
-          g.clamped[idx] = clampbits;
+          tiles_any = true;
+          rec0 = make_float4(pixx, pixy, conx, cony);
+          rec1 = make_float4(conz, op, rgb[0], rgb[1]);
+          rec2 = make_float4(rgb[2], pvz, hx, hy);
+          clamp_out = clampbits;
+
         }
       }
     }
-    radii_out[idx] = radius;  // the caller's array, or the blob's own when it passed none (launcher)
-    g.gpack[idx] = make_uint2(tiles, tiles ? rect_packed : 0u);
-    g.touched[idx] = 0;  // backward bookkeeping starts clean (the backward clears what it sets)
-    if (idx == 0) { g.total[2] = 0u; g.total[11] = 0u; }  // ([11]: no near budget crossed yet, k_scan_offsets)
-    // (key, value) pairs of the per-Gaussian depth sort; Gaussians without instances sort to the end
-    g.dkeysA[idx] = dkey;
-    g.order[idx] = (uint32_t)idx;
+  }
+  before_stores();  // (the loop takes over the next block's inputs here, see below)
+  radii_out[idx] = radius;  // the caller's array, or the blob's own when it passed none (launcher)
+  g.gpack[idx] = make_uint2(tiles, tiles ? rect_packed : 0u);
+  g.touched[idx] = 0;  // backward bookkeeping starts clean (the backward clears what it sets)
+  g.clamped[idx] = clamp_out;
+  // (key, value) pairs of the per-Gaussian depth sort; Gaussians without instances sort to the end
+  g.dkeysA[idx] = dkey;
+  g.order[idx] = (uint32_t)idx;
+  if (dup) { tiles = 0u; dkey = 0xFFFFFFFFu; }  // a duplicate lane is not counted below
+  {
+    // The 48-byte records of a wave's 64 Gaussians leave as three fully contiguous 1-KB stores: each lane parks its record
+    // in the wave's LDS image (stride 48 B: conflict-free) and stores float4 number lane + 64 k of the image.  Stored
+    // straight from the lane that computed it a record is three 16-byte pieces at a 48-byte stride -- every store
+    // instruction half-fills 64 sectors -- and the kernel spent 21 of its 74 us on these 83 MB (measured by leaving
+    // them out).  Wave-private, in program order: no barrier.
+#if GSR_PRE_VARIANT == 6
+    if (!dup && tiles_any) {
+      float4* rec = g.splats + (size_t)idx * SPLAT_F4;
+      rec[0] = rec0; rec[1] = rec1; rec[2] = rec2;
+    }
+#else
+    float4* img = s_rec[threadIdx.x >> 6];
+    const int lane = threadIdx.x & 63;
+    img[3 * lane + 0] = rec0;
+    img[3 * lane + 1] = rec1;
+    img[3 * lane + 2] = rec2;
+    // lanes exchange data here: without a (wave-scope) release / acquire pair the compiler reasons per thread -- a
+    // thread never reads its own img[3 lane + 1] back -- and deletes that store.  No instruction is emitted for it.
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the wave's first Gaussian (a wave wholly beyond P holds 64 copies of Gaussian P - 1's record: it re-stores that)
+    const int first = min(blk * PRE_BLOCK + (int)(threadIdx.x & ~63u), fp.P - 1);
+    const int nrec = min(64, fp.P - first) * SPLAT_F4;  // float4s of the image that belong to Gaussians (>= 3)
+    float4* dst = g.splats + (size_t)first * SPLAT_F4;
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+      const int j = min(lane + 64 * k, nrec - 1);       // (beyond the last record: its last float4 once more)
+      dst[j] = img[j];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the image is rewritten by the wave's next block)
+    __builtin_amdgcn_wave_barrier();
+#endif
   }
   if (!STAGED && ghist_acc) {
     // Gaussians without instances all carry the key 0xFFFFFFFF: counted per wave, not per lane (one address)
-    const bool has = idx < fp.P, none = has && dkey == 0xFFFFFFFFu;
+    const bool has = !dup, none = has && dkey == 0xFFFFFFFFu;
     const uint64_t nm = __ballot(none);
     if (has && !none) {
 #pragma unroll
@@ -413,6 +482,26 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     }
   }
   tiles_wg += tiles;
+  };
+  // Software pipeline over the blocks: the next block's inputs are requested before this block is worked on, and taken
+  // over -- the one place that has to wait for them -- AFTER this block's arithmetic and BEFORE its stores are issued.
+  // Loads and stores share one in-order counter: a wait placed behind the stores (where the compiler puts the loop-
+  // carried register copies by itself) would wait for the stores just issued, every block; placed here it waits for
+  // loads requested a whole block ago and stores issued a block ago.  The empty asm pins the take-over to this spot.
+  {
+    auto pin = [](In& v) {
+      asm volatile("" : "+v"(v.mx), "+v"(v.my), "+v"(v.mz), "+v"(v.s0), "+v"(v.s1), "+v"(v.s2), "+v"(v.op));
+      asm volatile("" : "+v"(v.dc0), "+v"(v.dc1), "+v"(v.dc2), "+v"(v.q.x), "+v"(v.q.y), "+v"(v.q.z), "+v"(v.q.w));
+    };
+    In a = fetch(blockIdx.x * PRE_BLOCK + threadIdx.x);
+    pin(a);  // (waited for here, so that the loop itself starts with nothing pending on these registers)
+    for (int blk = blockIdx.x; blk < nblk; blk += (int)gridDim.x) {
+      const In n = fetch((blk + (int)gridDim.x) * PRE_BLOCK + threadIdx.x);
+      work(a, blk, [&] {
+        a = n;
+        pin(a);
+      });
+    }
   }
   // side job: clear the depth sort's histograms, tickets and look-back status words
   for (size_t w = (size_t)blockIdx.x * PRE_BLOCK + threadIdx.x; w < g.dsort.nwords; w += (size_t)gridDim.x * PRE_BLOCK)
@@ -526,6 +615,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
   if (blockIdx.x == 0 && tid == 0) {
     g.total[12] = split ? 1u : 0u;  // marks the frame for the views (api.hip)
     g.total[8] = 0u;                // far-phase totals: a frame whose far chain is never enqueued has none
+    g.total[9] = 0u;
     g.total[10] = 0u;
   }
   // side job: (0, 0) for the tiles no instance lands in
@@ -1415,13 +1505,19 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps_k_preprocess(K_PREPROCESS, s);
   const size_t stage = (shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0;  // M > 1: SH rows go through LDS
-  // one resident round: 8 workgroups of 4 waves per CU (3 when 50 KB of LDS each hold SH rows) x 256 CUs, the
-  // blocks spread evenly over them (C3 measured: 6 per CU 101 us, 8 per CU 80 us, 16 per CU 93 us)
-  static const int wg_per_cu = getenv("GSR_PRE_WG_PER_CU") ? atoi(getenv("GSR_PRE_WG_PER_CU")) : 8;  // experiment knob
+  // one resident round: 4 workgroups of 4 waves per CU (3 when 50 KB of LDS each hold SH rows) x 256 CUs, the
+  // blocks spread evenly over them.  ~80 VGPRs allow five waves per SIMD, so more workgroups only queue up, and every
+  // workgroup ends with ~770 histogram flush atomics and one same-address count atomic (C3: 2, 3, 4, 8, 12, 16 per CU
+  // = 74, 71, 70, 75, 89, 105 us)
+  static const int wg_per_cu = getenv("GSR_PRE_WG_PER_CU") ? atoi(getenv("GSR_PRE_WG_PER_CU")) : 4;  // experiment knob
   const int max_wg = (stage ? 3 : wg_per_cu) * 256, rounds = (nb + max_wg - 1) / max_wg;
   const dim3 grid(rounds ? (nb + rounds - 1) / rounds : 1);
   if (stage)
     hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(PRE_BLOCK), stage, s, fp, means3D, scales, rotations, opacities,
+                       shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, write_cov3D, done_word, publish, ticket,
+                       ghist_acc, ghist_clear);
+  else if (fp.D == 0 && shs && scales && rotations && !cov3D_precomp && !colors_precomp && !write_cov3D)  // the product's configuration
+    hipLaunchKernelGGL((k_preprocess<false, true>), grid, dim3(PRE_BLOCK), 0, s, fp, means3D, scales, rotations, opacities,
                        shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, write_cov3D, done_word, publish, ticket,
                        ghist_acc, ghist_clear);
   else

@@ -95,6 +95,34 @@ __global__ __launch_bounds__(256) void k_sort_scan_top(uint32_t* __restrict__ ch
   if (lane == 0) digit_total[d] = carry;
 }
 
+// Both scans in ONE launch, for sorts of up to SCAN_COLUMNS_MAX workgroup tiles (8 M pairs: the near/far frames and
+// every frame below 1080p): grid = 64, block = 256, one wave per digit scans that digit's column of the per-tile
+// counts in place (exclusive), eight strided loads in flight per lane; the scatter pass then needs no chunk bases.
+// Beyond that size a column no longer fits a wave's few round trips and the two-level scan above is faster.
+constexpr int SCAN_COLUMNS_MAX = 2048;
+__global__ __launch_bounds__(256) void k_sort_scan_columns(uint32_t* __restrict__ counts, const int ntiles,
+                                                           uint32_t* __restrict__ digit_total) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int d = blockIdx.x * 4 + w;
+  uint32_t carry = 0;
+  for (int c0 = 0; c0 < ntiles; c0 += 512) {
+    uint32_t v[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int t = c0 + 64 * k + lane;
+      v[k] = t < ntiles ? counts[(size_t)t * 256 + d] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int t = c0 + 64 * k + lane;
+      const uint32_t inc = wave_incl_scan(v[k], lane);
+      if (t < ntiles) counts[(size_t)t * 256 + d] = carry + inc - v[k];
+      carry += __shfl(inc, 63, 64);
+    }
+  }
+  if (lane == 0) digit_total[d] = carry;
+}
+
 // All four digit histograms of the 32-bit keys in one pass over them (single-launch-per-pass sort below):
 // LDS atomics per workgroup, then one global atomicAdd per non-empty bin.  ghist[4][256] is zero on entry.
 __global__ __launch_bounds__(256) void k_sort_hist_all(const uint32_t* __restrict__ keys, int n,
@@ -232,6 +260,7 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
   const int passes = sort_passes(end_bit);
   const int nbits = sort_digit_bits(end_bit);
   const bool arank = lds_atomic_rank_ok(s);
+  static const bool two_level_scan = getenv("GSR_SORT_TWO_LEVEL_SCAN") != nullptr;  // diagnostics / fallback
   bool inA = start_in_A;
   for (int p = 0; p < passes; p++) {
     const K* kin = inA ? keysA : keysB;
@@ -243,39 +272,46 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
       ProfScope ps(K_SORT_HIST + kb, s);
       hipLaunchKernelGGL((k_sort_hist<K, TT>), dim3(ntiles), dim3(256), 0, s, kin, cnt, shift, nbits, sc.counts);
     }
-    {
+    const bool one_scan = ntiles <= SCAN_COLUMNS_MAX && !two_level_scan;
+    const uint32_t* chunk_base = one_scan ? nullptr : sc.chunk_sums;
+    if (one_scan) {
       ProfScope ps(K_SORT_SCAN_CHUNKS + kb, s);
-      hipLaunchKernelGGL(k_sort_scan_chunks, dim3(nchunks), dim3(256), 0, s, sc.counts, ntiles, sc.chunk_sums);
-    }
-    {
-      ProfScope ps(K_SORT_SCAN_TOP + kb, s);
-      hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, sc.chunk_sums, nchunks, sc.digit_base);
+      hipLaunchKernelGGL(k_sort_scan_columns, dim3(64), dim3(256), 0, s, sc.counts, ntiles, sc.digit_base);
+    } else {
+      {
+        ProfScope ps(K_SORT_SCAN_CHUNKS + kb, s);
+        hipLaunchKernelGGL(k_sort_scan_chunks, dim3(nchunks), dim3(256), 0, s, sc.counts, ntiles, sc.chunk_sums);
+      }
+      {
+        ProfScope ps(K_SORT_SCAN_TOP + kb, s);
+        hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, sc.chunk_sums, nchunks, sc.digit_base);
+      }
     }
     if (p == 0 && ef && sizeof(K) == 2) {  // the emitter generates the pairs inside the first pass
       ProfScope ps(K_SORT_SCATTER + kb, s);
       const hipError_t e = launch_emit_scatter(*ef, reinterpret_cast<uint16_t*>(kout), vout, nbits, sc.counts,
-                                               sc.chunk_sums, sc.digit_base, arank, s);
+                                               chunk_base, sc.digit_base, arank, s);
       if (e != hipSuccess) return e;
     } else if (key_count && p == passes - 1 && p > 0 && sizeof(K) == 2) {
       // last pass of the instance sort: per-key counts instead of the sorted keys (sort_core.hpp, COUNT)
       ProfScope ps(K_SORT_SCATTER + kb, s);
       if (arank)
         hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT, true>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout,
-                           vout, cnt, shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
+                           vout, cnt, shift, nbits, sc.counts, chunk_base, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr, key_count);
       else
         hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT, true>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout,
-                           vout, cnt, shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
+                           vout, cnt, shift, nbits, sc.counts, chunk_base, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr, key_count);
     } else {
       ProfScope ps(K_SORT_SCATTER + kb, s);
       if (arank)
         hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, cnt,
-                           shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
+                           shift, nbits, sc.counts, chunk_base, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
       else
         hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, cnt,
-                           shift, nbits, sc.counts, sc.chunk_sums, sc.digit_base, (uint32_t*)nullptr,
+                           shift, nbits, sc.counts, chunk_base, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
     }
     inA = !inA;

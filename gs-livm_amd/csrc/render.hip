@@ -197,14 +197,26 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
                                                       uint32_t* __restrict__ n_contrib,
                                                       uint32_t* __restrict__ quad_last, uint8_t* __restrict__ quad_done,
                                                       float* __restrict__ out_color,
-                                                      float* __restrict__ out_depth, float* __restrict__ out_acc) {
-  __shared__ float4 sAll[FW][3][64];  // wave-private images: no barrier anywhere in this kernel
+                                                      float* __restrict__ out_depth, float* __restrict__ out_acc,
+                                                      unsigned long long* __restrict__ done_word,
+                                                      unsigned long long* __restrict__ publish, const uint32_t ticket,
+                                                      uint32_t* __restrict__ live_quads_out) {
+  __shared__ float4 sAll[FW][3][64];  // wave-private images: no barrier in the blending itself
+  // PHASE 1 counts the quads it leaves unfinished and the launch's last workgroup hands the total to the host (api.hip:
+  // a frame whose far chain was not enqueued is complete iff that total is zero).  Finished waves per workgroup and
+  // their unfinished quads travel in one LDS word, finished workgroups and the running total in one 64-bit global word
+  // (as k_preprocess counts its instances): no fence, one same-address global atomic per workgroup.
+  __shared__ uint32_t s_done;
+  if (PHASE == 1) {
+    if (threadIdx.x == 0) s_done = 0u;
+    __syncthreads();  // the only barrier: at the start, where no wave waits for a slower one
+  }
   const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
   float4* sA = sAll[wq][0];
   float4* sB = sAll[wq][1];
   float4* sC = sAll[wq][2];
   const int quad = blockIdx.x * FW + wq;
-  if (quad >= fp.gx * fp.gy * 4) return;
+  if (quad >= fp.gx * fp.gy * 4) return;  // (never in PHASE 1: the grid covers exactly four quads per tile, FW = 4)
   const int tile = quad >> 2, q = quad & 3;
   const int tile_x = tile % fp.gx, tile_y = tile / fp.gx;
   const int qx = tile_x * TILE + (q & 1) * 8, qy = tile_y * TILE + (q >> 1) * 8;
@@ -318,7 +330,22 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
   if (lane == 0) quad_last[quad] = wl;
   if (PHASE == 1) {
     const bool all_stopped = __ballot(!done) == 0ull;
-    if (lane == 0) quad_done[quad] = all_stopped ? 1 : 0;
+    if (lane == 0) {
+      quad_done[quad] = all_stopped ? 1 : 0;
+      const uint32_t old = atomicAdd(&s_done, 1u | (all_stopped ? 0u : 0x100u));
+      if ((old & 0xFFu) == (uint32_t)FW - 1u) {  // last wave of this workgroup
+        const uint32_t mine = (old >> 8) + (all_stopped ? 0u : 1u);
+        const unsigned long long o = atomicAdd(done_word, (1ull << 40) | (unsigned long long)mine);
+        if ((o >> 40) == (unsigned long long)gridDim.x - 1ull) {  // last workgroup of the launch
+          const uint32_t live = (uint32_t)((o & ((1ull << 40) - 1ull)) + mine);
+          *live_quads_out = live;
+          __hip_atomic_store(done_word, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if (publish)
+            __hip_atomic_store(publish, ((unsigned long long)ticket << 32) | live, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+      }
+    }
     if (!all_stopped) {  // park the running state for phase 2
       if (inside) {
         final_T[pid] = T;
@@ -761,8 +788,7 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
 // the global-memory variant below walks rows and columns with dependent loads: 54 us).
 template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void k_live_sat(const uint8_t* __restrict__ quad_done, const int gx, const int gy,
-                                                   uint32_t* __restrict__ sat, uint32_t* __restrict__ total_live,
-                                                   unsigned long long* __restrict__ publish, const uint32_t ticket) {
+                                                   uint32_t* __restrict__ sat, uint32_t* __restrict__ total_live) {
   extern __shared__ uint32_t s_sat[];
   uint32_t* const S = IN_LDS ? s_sat : sat;
   const int sw = gx + 1, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -815,17 +841,10 @@ __global__ __launch_bounds__(1024) void k_live_sat(const uint8_t* __restrict__ q
   __syncthreads();
   if (IN_LDS)
     for (int i = tid; i < sw * (gy + 1); i += 1024) sat[i] = S[i];
-  if (tid == 0) {
-    const uint32_t live = S[gy * sw + gx];
-    *total_live = live;
-    // the host's copy (api.hip: a frame whose far chain was not enqueued is complete iff no tile is live)
-    if (publish)
-      __hip_atomic_store(publish, ((unsigned long long)ticket << 32) | live, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (tid == 0) *total_live = S[gy * sw + gx];
 }
 
-hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, unsigned long long* publish,
-                           uint32_t ticket, hipStream_t s) {
+hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, hipStream_t s) {
   ProfScope ps(K_LIVE_SAT, s);
   const size_t bytes = (size_t)(fp.gx + 1) * (fp.gy + 1) * sizeof(uint32_t);
   if (bytes <= 150 * 1024) {
@@ -833,16 +852,17 @@ hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(k_live_sat<true>, dim3(1), dim3(1024), bytes, s, im.quad_done, fp.gx, fp.gy, im.live_sat,
-                       total_live, publish, ticket);
+                       total_live);
   } else {
-    hipLaunchKernelGGL(k_live_sat<false>, dim3(1), dim3(1024), 0, s, im.quad_done, fp.gx, fp.gy, im.live_sat, total_live,
-                       publish, ticket);
+    hipLaunchKernelGGL(k_live_sat<false>, dim3(1), dim3(1024), 0, s, im.quad_done, fp.gx, fp.gy, im.live_sat, total_live);
   }
   return hipGetLastError();
 }
 
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
-                                float* out_color, float* out_depth, float* out_acc, int phase, hipStream_t s) {
+                                float* out_color, float* out_depth, float* out_acc, int phase,
+                                unsigned long long* done_word, unsigned long long* publish, uint32_t ticket,
+                                hipStream_t s) {
   ProfScope ps_k_blend_fwd(K_BLEND_FWD, s);
   // the four quads of a tile share a workgroup slot (they never synchronise): their redundant gathers of the same
   // records coincide in time and hit L1/L2; 1, 2 and 4 waves per workgroup measured within 3 % of each other
@@ -850,7 +870,7 @@ hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState
 #define GSR_LAUNCH_FWD(PH)                                                                                            \
   hipLaunchKernelGGL((k_blend_forward<4, PH>), dim3((quads + 3) / 4), dim3(256), 0, s, fp, im.ranges, im.rangesB,      \
                      b.point_list, g.splats, bg, im.final_T, im.n_contrib, im.quad_last, im.quad_done, out_color,      \
-                     out_depth, out_acc)
+                     out_depth, out_acc, done_word, publish, ticket, g.total + 13)
   if (phase == 1) GSR_LAUNCH_FWD(1);
   else if (phase == 2) GSR_LAUNCH_FWD(2);
   else GSR_LAUNCH_FWD(0);

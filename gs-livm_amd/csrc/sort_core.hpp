@@ -183,7 +183,8 @@ __device__ __forceinline__ void scatter_core(ScatterLds<K, NW, TILE>& L, uint32_
       gdelta[tid] = dbase + excl - lbase;
     } else {
       const int chunk = tile / SORT_CHUNK;
-      gdelta[tid] = dbase + chunk_base[(size_t)chunk * 256 + tid] + counts[(size_t)tile * 256 + tid] - lbase;
+      // (chunk_base == nullptr: the counts were scanned over all tiles in one launch, k_sort_scan_columns)
+      gdelta[tid] = dbase + (chunk_base ? chunk_base[(size_t)chunk * 256 + tid] : 0u) + counts[(size_t)tile * 256 + tid] - lbase;
     }
     }
   }

@@ -500,12 +500,14 @@ def test_huge_image_32bit_tile_keys(mode, gpu_device):
     assert fr.ranges.shape[0] == 257 * 257 and int(fr.ranges.max()) == fr.R
 
 
-@pytest.mark.parametrize("knob", ["GSR_SORT_BALLOT_RANK", "GSR_DEPTH_HIST_PASS", "GSR_RANGES_FROM_KEYS"])
+@pytest.mark.parametrize("knob", ["GSR_SORT_BALLOT_RANK", "GSR_DEPTH_HIST_PASS", "GSR_RANGES_FROM_KEYS",
+                                  "GSR_SORT_TWO_LEVEL_SCAN"])
 def test_sort_fallback_paths(knob, gpu_device):
     """The radix scatter ranks with returning LDS atomics only after a one-time probe of the hardware's conflict
     order; GSR_SORT_BALLOT_RANK=1 forces the ballot-match variant the library falls back to.  GSR_DEPTH_HIST_PASS=1
     makes the depth sort count its digits itself instead of taking the histograms k_preprocess counted;
-    GSR_RANGES_FROM_KEYS=1 derives the tile ranges from the sorted keys instead of the last pass's counts.  All are
+    GSR_RANGES_FROM_KEYS=1 derives the tile ranges from the sorted keys instead of the last pass's counts;
+    GSR_SORT_TWO_LEVEL_SCAN=1 scans the tile sort's digit counts in two launches as sorts beyond 8 M pairs do.  All are
     read once per process, so the check runs in a child process: bit-exact lists against the oracle there too
     (three forwards: the library-owned histogram buffers alternate between calls)."""
     import subprocess
