@@ -62,7 +62,7 @@ EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_byte
            "gsr_last_num_rendered", "gsr_set_binning_capacity_hint", "gsr_speculative_forwards",
            "gsr_speculation_overflows", "gsr_mailbox_slow_path_last", "gsr_set_near_far", "gsr_near_far",
            "gsr_last_near_far", "gsr_set_near_far_hints", "gsr_near_far_forwards", "gsr_set_far_speculation",
-           "gsr_last_far_skipped", "gsr_far_skips", "gsr_far_skip_misses")
+           "gsr_last_far_skipped", "gsr_far_skips", "gsr_far_skip_misses", "gsr_async_far_frames")
 
 
 def lib():
@@ -126,7 +126,7 @@ def lib():
     L.gsr_set_far_speculation.argtypes = [ci]
     L.gsr_last_far_skipped.restype = ci
     L.gsr_last_far_skipped.argtypes = []
-    for n in ("gsr_far_skips", "gsr_far_skip_misses"):
+    for n in ("gsr_far_skips", "gsr_far_skip_misses", "gsr_async_far_frames"):
         getattr(L, n).restype = C.c_ulonglong
         getattr(L, n).argtypes = []
     L.gsr_mailbox_slow_path_last.restype = ci
@@ -279,7 +279,7 @@ def speculation_stats():
     L = lib()
     return dict(speculative_forwards=int(L.gsr_speculative_forwards()), overflows=int(L.gsr_speculation_overflows()),
                 near_far_forwards=int(L.gsr_near_far_forwards()), far_skips=int(L.gsr_far_skips()),
-                far_skip_misses=int(L.gsr_far_skip_misses()),
+                far_skip_misses=int(L.gsr_far_skip_misses()), async_far_frames=int(L.gsr_async_far_frames()),
                 mailbox_slow_path_hits=int(L.gsr_mailbox_slow_path_hits()))
 
 

@@ -45,6 +45,7 @@ static int fail(int code, const char* fmt, ...) {
 namespace gsr {
 std::atomic<bool> g_prof_on{false};
 std::atomic<unsigned long long> g_prof_mask{~0ull};
+thread_local bool t_prof_suppress = false;
 static std::mutex g_ev_mu;            // guards the pool: the reference calls the rasterizer from several threads
 static std::vector<hipEvent_t> g_ev;  // pool: [2*i] start, [2*i+1] stop
 static std::vector<int> g_ev_id;
@@ -210,6 +211,15 @@ struct ThreadCtx {
   int far_idle_streak = 0;                    // consecutive near/far frames of this thread that left no tile live
   int far_skip_override = -1;                 // gsr_set_far_speculation: -1 auto, 0 never, 1 the next split forward
   bool last_far_skipped = false;
+  // asynchronous near/far frames: a second stream for the far chain, three signal words (0 decide, 1 go), a sequence
+  // number, and what the last such frame left to be read from the mailbox once it has got there
+  hipStream_t far_stream = nullptr;
+  uint32_t* sig_decide = nullptr;             // 2 seq + (far chain needed ? 1 : 0), stored by the near blend
+  uint32_t* sig_go = nullptr;                 // seq once the frame is complete
+  uint32_t async_seq = 0;
+  int async_state = 0;                        // 0 not probed, 1 usable, -1 unavailable
+  bool lazy_pending = false;                  // the last forward returned before its far-chain decision was known
+  uint32_t lazy_ticket = 0, lazy_near = 0;
   const uint32_t* top_hist = nullptr;         // this forward's [count | tile sum] by top key byte (k_preprocess), or null
 };
 static thread_local ThreadCtx g_ctx;
@@ -232,12 +242,15 @@ static int ctx_prepare(ThreadCtx& c, hipStream_t stream) {
     c.ticket = 0;
     c.hist_flip = 0;
     c.used = false;
+    c.async_state = 0;  // (a previous device's stream and signal words stay allocated: switching is rare)
+    c.lazy_pending = false;
     for (int k = 0; k < 8; k++) c.mailbox[k] = 0;  // word 0: num_rendered; near/far frames: 1 = far count, 2 = near count
     (void)hipDeviceSynchronize();  // the counter is zero before any stream uses it
   }
   if (c.used && stream != c.last_stream) {
     // this thread's previous forward ran on another stream: its k_preprocess may still be counting into the words
     HIP_TRY(hipStreamSynchronize(c.last_stream));
+    if (c.far_stream) HIP_TRY(hipStreamSynchronize(c.far_stream));
   }
   c.last_stream = stream;
   c.used = true;
@@ -317,7 +330,72 @@ static bool order_known(const char* blob) {
     if (e == blob) return true;
   return false;
 }
-static std::atomic<unsigned long long> g_far_skips{0}, g_far_skip_misses{0};
+// ---- asynchronous near/far frames ------------------------------------------------------------------------------
+// Stream-side hand-off instead of a host round trip (hipStreamWaitValue32, where the device offers it): the far chain
+// is enqueued on the library's own stream behind a wait for the near blend's decision word, every kernel of it gated
+// on "needed", and the caller's stream waits for the frame's go word -- which the near blend itself stores when no
+// quad was left unfinished.  The host never waits for the decision.  GSR_ASYNC_FAR=0 switches the mechanism off (the
+// host then reads the count of unfinished quads from the mailbox and enqueues the far chain if there are any).
+static bool async_far_ready(ThreadCtx& c) {
+  if (c.async_state) return c.async_state > 0;
+  c.async_state = -1;
+  const char* e = getenv("GSR_ASYNC_FAR");
+  if (e && e[0] == '0') return false;
+  int can = 0;
+  if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c.device) != hipSuccess || !can) {
+    (void)hipGetLastError();
+    return false;
+  }
+  void *a = nullptr, *b = nullptr;
+  hipStream_t st = nullptr;
+  if (hipExtMallocWithFlags(&a, 8, hipMallocSignalMemory) != hipSuccess ||
+      hipExtMallocWithFlags(&b, 8, hipMallocSignalMemory) != hipSuccess || hipMemset(a, 0, 8) != hipSuccess ||
+      hipMemset(b, 0, 8) != hipSuccess || hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+    (void)hipGetLastError();
+    if (a) (void)hipFree(a);
+    if (b) (void)hipFree(b);
+    return false;
+  }
+  (void)hipDeviceSynchronize();
+  c.sig_decide = static_cast<uint32_t*>(a);
+  c.sig_go = static_cast<uint32_t*>(b);
+  c.far_stream = st;
+  c.async_seq = 0;
+  c.async_state = 1;
+  return true;
+}
+
+static bool peek_word(const ThreadCtx& c, int word, uint32_t ticket, uint32_t* out) {
+  const unsigned long long v = __atomic_load_n(c.mailbox + word, __ATOMIC_ACQUIRE);
+  if ((uint32_t)(v >> 32) != ticket) return false;
+  *out = (uint32_t)v;
+  return true;
+}
+
+static std::atomic<unsigned long long> g_far_skips{0}, g_far_skip_misses{0}, g_async_frames{0};
+
+// What an asynchronous frame left open when gsr_forward returned -- did its far chain run, and over how many
+// instances -- is read from the mailbox the next time the thread asks (never waited for).
+static void lazy_resolve(ThreadCtx& c) {
+  if (!c.lazy_pending) return;
+  uint32_t live = 0, far = 0;
+  if (!peek_word(c, 3, c.lazy_ticket, &live)) return;
+  if (live != 0u && !peek_word(c, 1, c.lazy_ticket, &far)) return;
+  c.lazy_pending = false;
+  c.last_far = far;
+  c.last_far_skipped = live == 0u;
+  c.recent_far[c.recent_far_pos] = far;
+  c.recent_far_pos = (c.recent_far_pos + 1) & 3;
+  c.have_far = true;
+  if (live == 0u) {
+    ++g_far_skips;
+    c.far_idle_streak++;
+  } else {
+    ++g_far_skip_misses;
+    c.far_idle_streak = 0;
+  }
+  c.last_R = c.last_near + c.last_far;
+}
 
 // One binning chain: scan -> emit -> tile sort -> ranges, followed by the blend.  A whole frame is one chain over the
 // blob (phase 0).  A near/far frame (gsr_forward) runs two chains over ONE blob carved for capA + capB instances:
@@ -332,8 +410,8 @@ struct Chain {
 
 static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, BinningState& b, const Chain& ch,
                          ThreadCtx& c, const float* background, float* out_color, float* out_depth, float* out_acc,
-                         int debug, hipStream_t stream) {
-  const Count cnt = ch.cnt;
+                         int debug, hipStream_t stream, AsyncWords aw = AsyncWords()) {
+  const Count cnt = ch.cnt;  // (carries the gate of an asynchronous frame's far chain)
   const int tiles = fp.gx * fp.gy;
   const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
   const bool start_in_A = (sort_passes(tile_bits) % 2) == 0;
@@ -345,8 +423,8 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
   uint8_t* inst_flag = b.inst_flag + ch.base;
   uint2* ranges = far ? im.rangesB : im.ranges;
   if (far) {
-    STAGE(launch_live_sat(fp, im, g.total + 9, stream));  // which tiles did the near chain leave unfinished
-    STAGE(launch_scan_offsets_far(fp, g, cnt.cap, ch.base, im.live_sat, chunk_first, b.tsort.counts, c.mailbox_dev + 1,
+    STAGE(launch_live_sat(fp, im, g.total + 9, cnt, stream));  // which tiles did the near chain leave unfinished
+    STAGE(launch_scan_offsets_far(fp, g, cnt, ch.base, im.live_sat, chunk_first, b.tsort.counts, c.mailbox_dev + 1,
                                   c.ticket, stream));
   }
   else
@@ -366,7 +444,7 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
                           /*is_depth_sort=*/false, key16, /*first_hist_done=*/true, key16 ? &ef : nullptr,
                           count_ranges ? reinterpret_cast<uint32_t*>(ranges) : nullptr, stream));
   if (count_ranges)
-    STAGE(launch_ranges_from_counts(ranges, tiles, ch.base, stream));
+    STAGE(launch_ranges_from_counts(ranges, tiles, ch.base, cnt, stream));
   else
     STAGE(launch_tile_ranges(b.tkeysA, cnt, ranges, key16, ch.base, stream));
   if (debug && ch.phase == 0) {  // self-check of the binning chain: every list ordered by (depth bits, id)
@@ -378,7 +456,7 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
   }
   // (the near blend counts the quads it leaves unfinished into the host's mailbox: done word 1, mailbox word 3)
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, ch.phase, c.done_counter + 1,
-                             c.mailbox_dev + 3, c.ticket, stream));
+                             c.mailbox_dev + 3, c.ticket, ch.phase == 1 ? aw : AsyncWords(), cnt, stream));
   return GSR_OK;
 }
 
@@ -447,6 +525,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   //     waits for the host.  If R exceeds the capacity the kernels have clamped to it (in-bounds garbage); the
   //     host then allocates an exact blob and enqueues the binning chain again -- the only cost of a misprediction.
   ThreadCtx& c = g_ctx;
+  lazy_resolve(c);  // (what the thread's previous asynchronous frame left open, if the mailbox has it by now)
+  c.lazy_pending = false;
   {
     const int rc = ctx_prepare(c, stream);
     if (rc != GSR_OK) return rc;
@@ -526,7 +606,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       const uint32_t budget = (uint32_t)budget64;
       const uint32_t capA = budget + (uint32_t)tiles_n;  // the run the budget falls into ends at most one rectangle later
       uint32_t capB = 0;
-      if (c.far_hint_override >= 0) {
+      const bool capB_forced = c.far_hint_override >= 0;  // (test hook: may be too small on purpose)
+      if (capB_forced) {
         capB = (uint32_t)c.far_hint_override;
         c.far_hint_override = -1;
       } else if (c.have_far) {
@@ -535,28 +616,68 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       } else {
         capB = hint > budget ? hint - budget : 0u;  // no history: room for every instance behind the budget
       }
+      // Far-chain speculation.  In a dense scene the near chain finishes every quad, frame after frame, and the far
+      // chain's launches find nothing to do (~60 us at 1080p).  After two such frames in a row (or when the test hook
+      // asks) the thread's next split frame is
+      //   * ASYNCHRONOUS where the device has stream-side waits (async_far_ready): the far chain goes to the library's
+      //     own stream behind a wait for the near blend's decision, every kernel of it gated on "quads were left
+      //     unfinished"; the caller's stream waits for the frame's go word, which the near blend's last workgroup stores
+      //     itself when nothing is left to do (otherwise the far chain's last kernel does).  Nobody waits for the
+      //     decision on the host; with no host in the loop the far segment is sized for every instance behind the near
+      //     budget, so it cannot overflow;
+      //   * otherwise decided by the host: the near blend publishes the count of unfinished quads to the mailbox and the
+      //     far chain is enqueued only if there are any (one host round trip instead of eleven idle launches).
+      // The near blend parks the unfinished pixels' state in the same way in every variant: same result.
+      const bool speculate_far = c.far_skip_override >= 0 ? c.far_skip_override == 1 : c.far_idle_streak >= 2;
+      if (c.far_skip_override == 1) c.far_skip_override = -1;
+      const bool async_far = speculate_far && async_far_ready(c);
+      const bool skip_far = speculate_far && !async_far;
+      if (async_far && !capB_forced) capB = std::max(capB, hint > budget ? hint - budget : 0u);
       if (capB < 4096u) capB = 4096u;
+      if ((unsigned long long)capA + capB > 0x7fffffffull) capB = 0x7fffffffu - capA;
       key = (int)(capA + capB);
       char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
       if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
       BinningState b = BinningState::carve(bblob, (size_t)key);
+      AsyncWords aw;
+      if (async_far) {
+        if (c.async_seq >= 0x3FFFFFF0u) {  // (the decision word carries 2 seq + 1)
+          HIP_TRY(hipStreamSynchronize(stream));
+          HIP_TRY(hipStreamSynchronize(c.far_stream));
+          HIP_TRY(hipMemset(c.sig_decide, 0, 8));
+          HIP_TRY(hipMemset(c.sig_go, 0, 8));
+          HIP_TRY(hipMemset(c.done_counter + 2, 0, 8));
+          c.async_seq = 0;
+        }
+        aw.decide = c.sig_decide;
+        aw.go = c.sig_go;
+        aw.gate_dev = reinterpret_cast<uint32_t*>(c.done_counter + 2);
+        aw.seq = ++c.async_seq;
+      }
       int rc = enqueue_chain(fp, g, im, b, Chain{1, Count{g.total + 6, (int)capA}, budget, 0u}, c, background, out_color,
-                             out_depth, out_acc, debug, stream);
+                             out_depth, out_acc, debug, stream, aw);
       if (rc != GSR_OK) return rc;
-      // Far-chain speculation.  In a dense scene the near chain finishes every tile, frame after frame, and the far
-      // chain's eleven launches find nothing to do (~60 us at 1080p).  After two such frames in a row the forward
-      // stops after the near chain: the near blend's last workgroup publishes the number of unfinished quads, the backward's tile order is
-      // computed here (it fills the time until the host has enqueued its next kernels), and the host reads the word.
-      // No live tile: the frame is complete -- every quad was finished by the near blend.  Otherwise (a
-      // misprediction: one host round trip) the far chain is enqueued now; the near blend has parked the unfinished
-      // pixels' state exactly as for a far chain enqueued at once, so the result is the same.
-      const bool skip_far = c.far_skip_override >= 0 ? c.far_skip_override == 1 : c.far_idle_streak >= 2;
-      if (c.far_skip_override == 1) c.far_skip_override = -1;
-      const Chain far_chain{2, Count{g.total + 8, (int)capB}, 0xFFFFFFFFu, capA};
+      Chain far_chain{2, Count{g.total + 8, (int)capB}, 0xFFFFFFFFu, capA};
       uint32_t live = 0;
       c.last_far_skipped = false;
-      if (skip_far) {
-        if ((rc = launch_tile_order(fp, im, stream)) != hipSuccess) return fail(GSR_ERR_HIP, "k_tile_order launch failed");
+      c.lazy_pending = false;
+      if (async_far) {
+        far_chain.cnt.gate = aw.gate_dev;
+        far_chain.cnt.gate_open = 2u * aw.seq + 1u;
+        HIP_TRY(hipStreamWaitValue32(c.far_stream, c.sig_decide, 2u * aw.seq, hipStreamWaitValueGte));
+        // (not timed by the event profiler: the chain waits on its stream for the decision and then, as a rule, only
+        // launches and leaves; its kernels run beside the other stream's and would be booked twice)
+        t_prof_suppress = true;
+        rc = enqueue_chain(fp, g, im, b, far_chain, c, background, out_color, out_depth, out_acc, debug, c.far_stream);
+        t_prof_suppress = false;
+        if (rc != GSR_OK) return rc;
+        HIP_TRY(launch_release_go(far_chain.cnt, c.sig_go, aw.seq, c.far_stream));
+        HIP_TRY(hipStreamWaitValue32(stream, c.sig_go, aw.seq, hipStreamWaitValueGte));
+        HIP_TRY(launch_tile_order(fp, im, stream));  // (after the go word: the far chain may move quad_last)
+        order_remember(iblob);
+        ++g_async_frames;
+      } else if (skip_far) {
+        if (launch_tile_order(fp, im, stream) != hipSuccess) return fail(GSR_ERR_HIP, "k_tile_order launch failed");
       } else {
         rc = enqueue_chain(fp, g, im, b, far_chain, c, background, out_color, out_depth, out_acc, debug, stream);
         if (rc != GSR_OK) return rc;
@@ -564,32 +685,47 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       const std::chrono::steady_clock::time_point tw = std::chrono::steady_clock::now();
       if ((rc = wait_num_rendered(c, stream, &R_host)) != GSR_OK) return rc;
       if ((rc = wait_num_rendered(c, stream, &R_near, 2)) != GSR_OK) return rc;
-      if ((rc = wait_num_rendered(c, stream, &live, 3)) != GSR_OK) return rc;
-      if (skip_far && live == 0u) {
-        ++g_far_skips;
-        c.last_far_skipped = true;
-        order_remember(iblob);
+      bool know_far = true;
+      if (async_far && (unsigned long long)R_host - R_near <= (unsigned long long)capB) {
+        // the far segment holds whatever the far chain may emit: nothing left for the host to check or to wait for
+        know_far = false;
+        c.lazy_pending = true;
+        c.lazy_ticket = c.ticket;
         R_far = 0;
       } else {
-        if (skip_far) {  // live tiles after all
-          ++g_far_skip_misses;
-          rc = enqueue_chain(fp, g, im, b, far_chain, c, background, out_color, out_depth, out_acc, debug, stream);
-          if (rc != GSR_OK) return rc;
+        if ((rc = wait_num_rendered(c, stream, &live, 3)) != GSR_OK) return rc;
+        if (skip_far && live == 0u) {
+          ++g_far_skips;
+          c.last_far_skipped = true;
+          order_remember(iblob);
+          R_far = 0;
+        } else if (async_far && live == 0u) {
+          R_far = 0;
+          c.last_far_skipped = true;
+        } else {
+          if (skip_far) {  // unfinished quads after all
+            ++g_far_skip_misses;
+            rc = enqueue_chain(fp, g, im, b, far_chain, c, background, out_color, out_depth, out_acc, debug, stream);
+            if (rc != GSR_OK) return rc;
+          }
+          if ((rc = wait_num_rendered(c, stream, &R_far, 1)) != GSR_OK) return rc;
         }
-        if ((rc = wait_num_rendered(c, stream, &R_far, 1)) != GSR_OK) return rc;
+        c.far_idle_streak = live == 0u ? c.far_idle_streak + 1 : 0;
       }
-      c.far_idle_streak = live == 0u ? c.far_idle_streak + 1 : 0;
       if (host_trace)
         fprintf(stderr, "[gsr] near/far forward: capacity %u + %u, near %u, far %u of %u instances, %u unfinished quads%s, "
                         "enqueue %.1f us, then waited %.1f us\n", capA, capB, R_near, R_far, R_host, live,
-                skip_far ? (live ? " (far chain enqueued late)" : " (far chain not enqueued)") : "",
+                async_far ? (know_far ? " (asynchronous far chain, checked by the host)" : " (asynchronous far chain)")
+                : skip_far ? (live ? " (far chain enqueued late)" : " (far chain not enqueued)") : "",
                 std::chrono::duration<double, std::micro>(tw - t_enq).count(),
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count());
       ++g_speculative_forwards;
       ++g_near_far_forwards;
-      c.recent_far[c.recent_far_pos] = R_far;
-      c.recent_far_pos = (c.recent_far_pos + 1) & 3;
-      c.have_far = true;
+      if (know_far) {
+        c.recent_far[c.recent_far_pos] = R_far;
+        c.recent_far_pos = (c.recent_far_pos + 1) & 3;
+        c.have_far = true;
+      }
       c.last_was_near_far = true;
       redo = R_far > capB;
     } else {
@@ -635,16 +771,23 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     c.last_near = R_near;
     c.last_far = R_far;
   }
+  if (host_trace)
+    fprintf(stderr, "[gsr] forward returns at %.1f us (process clock)\n",
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count());
   c.recent[c.recent_pos] = R_host;  // (all instances of the frame, emitted or not: what a one-chain frame needs)
   c.recent_pos = (c.recent_pos + 1) & 3;
   c.last_R = c.last_near + c.last_far;  // the instances this forward emitted, sorted and ranged
   return key;
 }
 
-int gsr_last_num_rendered(void) { return (int)g_ctx.last_R; }
+int gsr_last_num_rendered(void) {
+  lazy_resolve(g_ctx);
+  return (int)g_ctx.last_R;
+}
 int gsr_set_near_far(int on) { return near_far_flag().exchange(on != 0 ? 1 : 0); }
 int gsr_near_far(void) { return near_far_flag().load(); }
 int gsr_last_near_far(unsigned* near_instances, unsigned* far_instances) {
+  lazy_resolve(g_ctx);
   if (near_instances) *near_instances = g_ctx.last_near;
   if (far_instances) *far_instances = g_ctx.last_far;
   return g_ctx.last_was_near_far ? 1 : 0;
@@ -661,7 +804,11 @@ int gsr_set_far_speculation(int mode) {
   if (mode < 0) g_ctx.far_idle_streak = 0;
   return prev;
 }
-int gsr_last_far_skipped(void) { return g_ctx.last_far_skipped ? 1 : 0; }
+int gsr_last_far_skipped(void) {
+  lazy_resolve(g_ctx);
+  return g_ctx.last_far_skipped ? 1 : 0;
+}
+unsigned long long gsr_async_far_frames(void) { return g_async_frames.load(); }
 unsigned long long gsr_far_skips(void) { return g_far_skips.load(); }
 unsigned long long gsr_far_skip_misses(void) { return g_far_skip_misses.load(); }
 long long gsr_set_binning_capacity_hint(long long capacity) {
@@ -702,6 +849,10 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
   if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
       (M > 0 && !dL_dsh))
     return fail(GSR_ERR_INVALID_ARGUMENT, "null gradient output");
+  static const bool host_trace_b = getenv("GSR_HOST_TRACE") != nullptr;
+  if (host_trace_b)
+    fprintf(stderr, "[gsr] backward entered at %.1f us (process clock)\n",
+            std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count());
   const FrameParams fp = make_params(P, D, M, width, height, tan_fovx, tan_fovy, scale_modifier);
   GeomState g = GeomState::carve(geom_buffer, (size_t)P);
   BinningState b = BinningState::carve(binning_buffer, (size_t)R);

@@ -225,9 +225,21 @@ struct BinningState {
 // the synchronous forward).  Otherwise the host has sized grids and buffers for `cap` instances WITHOUT waiting for the
 // count (api.hip, speculative forward) and every kernel reads it from device memory, clamped to `cap` -- an overflowing
 // frame then produces in-bounds garbage that the host discards and redoes with the exact count.
+// Gate (asynchronous near/far frames, api.hip): the far chain of such a frame is enqueued on a second stream before
+// anyone knows whether it is needed; the near blend's last workgroup decides and stores 2 * seq + (needed ? 1 : 0) into
+// a library-owned device word (and into the signal word the stream waits for).  Every kernel of that chain carries
+// the device word and the value that opens it and leaves at once -- touching nothing: the blobs may already be in use
+// by the backward, or freed -- when the word says anything else (seq only grows: a stale kernel never finds it open).
 struct Count {
   const uint32_t* dev;
   int cap;
+  const uint32_t* gate = nullptr;
+  uint32_t gate_open = 0;
+  // (the word is device memory and is read like the count below -- it was stored, write-through, before the stream
+  // wait that precedes this kernel's launch was satisfied.  Tens of thousands of workgroups ask: an agent-scope atomic
+  // load each serialises on the one address -- 0.14 ms for the 62 000 waves of an idle k_emit -- and a load from the
+  // host-visible signal word itself stalled them long enough to starve the other stream's kernels of wave slots.)
+  __device__ __forceinline__ bool closed() const { return gate && __builtin_nontemporal_load(gate) != gate_open; }
   __device__ __forceinline__ int get() const {
     if (!dev) return cap;
     const uint32_t v = __builtin_nontemporal_load(dev);
@@ -235,6 +247,25 @@ struct Count {
   }
 };
 
+// Work units of a binning kernel (emit chunks, sort tiles) are walked with a grid stride: a chain whose capacity is
+// known to be used launches one workgroup per unit (the loop runs once), the gated far chain of an asynchronous frame
+// -- capacity = every instance behind the near budget, almost always unused -- launches at most GATED_GRID_MAX
+// workgroups per kernel, so that an idle chain costs a few hundred workgroup launches instead of ~40 000 that compete
+// with the other stream's kernels for wave slots.  `f(unit)` may return early (workgroup-uniformly).
+constexpr int GATED_GRID_MAX = 1024;
+template <typename F>
+__device__ __forceinline__ void for_each_unit(const int nunits, F&& f) {
+  for (int unit = blockIdx.x; unit < nunits; unit += gridDim.x) {
+    f(unit);
+    __syncthreads();  // (the unit's LDS is reused by the next one)
+  }
+}
+__host__ __device__ inline int units_of(int n, int per) { return (int)(((long long)n + per - 1) / per); }
+// workgroups to launch for a chain's kernel whose work unit covers `per` instances
+inline int chain_grid(const Count& c, int per) {
+  const int u = units_of(c.cap, per);
+  return c.gate && u > GATED_GRID_MAX ? GATED_GRID_MAX : u;
+}
 struct FrameParams {
   int P, D, M, W, H, gx, gy;
   float tan_fovx, tan_fovy, focal_x, focal_y, scale_modifier;
@@ -253,7 +284,7 @@ hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t 
 hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint2* ranges,
                                uint2* rangesB, uint32_t* counts0, uint32_t near_budget,
                                unsigned long long* publish_near, uint32_t ticket, const uint32_t* top_hist, hipStream_t s);
-hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, int capB, uint32_t slot_base, const uint32_t* sat,
+hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, Count capB, uint32_t slot_base, const uint32_t* sat,
                                    uint32_t* chunk_firstB, uint32_t* counts0, unsigned long long* publish,
                                    uint32_t ticket, hipStream_t s);
 hipError_t launch_emit(const FrameParams& fp, const uint4* sdesc, Count R, uint32_t* chunk_first, uint32_t* tkeys_out,
@@ -279,15 +310,24 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
                              hipStream_t s);
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
                              int n, const uint32_t* ghist, hipStream_t s);
-hipError_t launch_ranges_from_counts(uint2* ranges, int T, uint32_t list_base, hipStream_t s);
+hipError_t launch_ranges_from_counts(uint2* ranges, int T, uint32_t list_base, Count gate, hipStream_t s);
 hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t* point_list, const float4* splats,
                                       uint32_t* violations, hipStream_t s);
 hipError_t launch_tile_ranges(const uint32_t* tile_ids, Count R, uint2* ranges, bool key16, uint32_t list_base, hipStream_t s);
+// (decide / go / seq: asynchronous near/far frames, phase 1 -- the near blend's last workgroup stores
+// 2 seq + (quads left unfinished ? 1 : 0) into *decide and, if none is, seq into *go; gate: phase 2)
+struct AsyncWords {
+  uint32_t* decide = nullptr;    // signal memory: what the far chain's stream waits for
+  uint32_t* go = nullptr;        // signal memory: what the caller's stream waits for
+  uint32_t* gate_dev = nullptr;  // device memory: the decision again, for the gates (Count::closed)
+  uint32_t seq = 0;
+};
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, int phase,
                                 unsigned long long* done_word, unsigned long long* publish, uint32_t ticket,
-                                hipStream_t s);
-hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, hipStream_t s);
+                                AsyncWords aw, Count gate, hipStream_t s);
+hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, Count gate, hipStream_t s);
+hipError_t launch_release_go(Count gate, uint32_t* go, uint32_t seq, hipStream_t s);
 hipError_t launch_tile_order(const FrameParams& fp, ImageState im, hipStream_t s);
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                  const float* dL_dpix, const float* dL_dacc, bool have_tile_order, hipStream_t s);
@@ -340,11 +380,13 @@ void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);
 extern std::atomic<bool> g_prof_on;
 extern std::atomic<unsigned long long> g_prof_mask;  // bit i: kernel id i is recorded
+extern thread_local bool t_prof_suppress;             // launches that are not timed (an asynchronous frame's gated chain)
 struct ProfScope {  // records a start/stop event pair around the launches in its scope while profiling is on
   hipStream_t s;
   bool on;
   ProfScope(int id, hipStream_t st)
-      : s(st), on(g_prof_on.load(std::memory_order_relaxed) && ((g_prof_mask.load(std::memory_order_relaxed) >> id) & 1ull)) {
+      : s(st), on(!t_prof_suppress && g_prof_on.load(std::memory_order_relaxed) &&
+                  ((g_prof_mask.load(std::memory_order_relaxed) >> id) & 1ull)) {
     if (on) prof_begin(id, s);
   }
   ~ProfScope() { if (on) prof_end(s); }

@@ -197,9 +197,6 @@ static inline size_t sh_stage_bytes(int M) {
 // branch with a load in it ends in an `s_waitcnt vmcnt(0)` at the join -- vector loads return in order, so that wait
 // also waits for the NEXT block's inputs requested at the top of the iteration, and the prefetch never overlaps the
 // arithmetic.  With the branches compiled away no load is issued between the prefetch and the next iteration.
-#ifndef GSR_PRE_VARIANT
-#define GSR_PRE_VARIANT 0
-#endif
 template <bool STAGED, bool PLAIN = false>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     const FrameParams fp, const float* __restrict__ means3D, const float* __restrict__ scales,
@@ -285,7 +282,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   uint32_t tiles = 0, rect_packed = 0, dkey = 0xFFFFFFFFu;
   int radius = 0;
   float4 rec0 = make_float4(0.f, 0.f, 0.f, 0.f), rec1 = rec0, rec2 = rec0;  // splat record (zeros for a culled Gaussian)
-  bool tiles_any = false; (void)tiles_any;
   uint8_t clamp_out = 0;
   {
     const float mx = in.mx, my = in.my, mz = in.mz;
@@ -412,7 +408,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
           tiles = (x1 > x0 && y1 > y0) ? (uint32_t)((x1 - x0) * (y1 - y0)) : 0u;
           rect_packed = (uint32_t)x0 | ((uint32_t)y0 << 10) | ((uint32_t)(x1 - x0) << 20);
           if (tiles) dkey = __float_as_uint(pvz);  // depth > 0.2: the bit pattern orders like the value
-          tiles_any = true;
           rec0 = make_float4(pixx, pixy, conx, cony);
           rec1 = make_float4(conz, op, rgb[0], rgb[1]);
           rec2 = make_float4(rgb[2], pvz, hx, hy);
@@ -437,12 +432,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     // straight from the lane that computed it a record is three 16-byte pieces at a 48-byte stride -- every store
     // instruction half-fills 64 sectors -- and the kernel spent 21 of its 74 us on these 83 MB (measured by leaving
     // them out).  Wave-private, in program order: no barrier.
-#if GSR_PRE_VARIANT == 6
-    if (!dup && tiles_any) {
-      float4* rec = g.splats + (size_t)idx * SPLAT_F4;
-      rec[0] = rec0; rec[1] = rec1; rec[2] = rec2;
-    }
-#else
     float4* img = s_rec[threadIdx.x >> 6];
     const int lane = threadIdx.x & 63;
     img[3 * lane + 0] = rec0;
@@ -464,7 +453,6 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the image is rewritten by the wave's next block)
     __builtin_amdgcn_wave_barrier();
-#endif
   }
   if (!STAGED && ghist_acc) {
     // Gaussians without instances all carry the key 0xFFFFFFFF: counted per wave, not per lane (one address)
@@ -774,7 +762,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
 // the sentinel, and the host's second mailbox word).
 constexpr unsigned long long SF_GLOBAL = 2ull << 62, SF_LOCAL = 1ull << 62, SF_MASK = (1ull << 62) - 1ull;
 
-__global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets_far(const FrameParams fp, GeomState g, const int capB,
+__global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets_far(const FrameParams fp, GeomState g, const Count capB_,
                                                                 const uint32_t slot_base,
                                                                 const uint32_t* __restrict__ sat,
                                                                 uint32_t* __restrict__ chunk_firstB,
@@ -784,6 +772,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets_far(const FrameParam
   __shared__ unsigned long long wtot[PRE_BLOCK / 64];
   __shared__ uint32_t s_tile;
   __shared__ unsigned long long s_prefix;
+  if (capB_.closed()) return;  // (asynchronous frame that needs no far chain)
+  const int capB = capB_.cap;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   // side job: clear the digit counts of the far tile sort's first pass
   for (size_t q = (size_t)blockIdx.x * PRE_BLOCK + tid; q < ncounts0; q += (size_t)gridDim.x * PRE_BLOCK) counts0[q] = 0u;
@@ -964,9 +954,9 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, cons
   };
   __shared__ SMem sm;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  const int tile = blockIdx.x;
+  if (cnt.closed()) return;
   const int R = cnt.get();
-  if ((size_t)tile * TSORT_TILE >= (size_t)R) return;  // (grid sized for the capacity)
+  for_each_unit(units_of(R, TSORT_TILE), [&](const int tile) {
   uint32_t tk[2][8], iv[2][8];
 #pragma unroll
   for (int r = 0; r < 2; r++) {
@@ -1011,6 +1001,7 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, cons
   __syncthreads();
   scatter_core<uint16_t, false, ARANK, TSORT_WAVES, TSORT_TILE>(sm.L, key, val, tile, keys_out, vals_out, R, 0, nbits0,
                                                                 counts, chunk_base, digit_total, nullptr);
+  });
 }
 
 // STORE = false: count-only emitter in front of k_emit_scatter (digit counts + inst_flag reset, no pair stores)
@@ -1023,12 +1014,13 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, const uint4*
   __shared__ EmitStage st;
   __shared__ uint32_t hist[256];  // digit counts of the tile sort's FIRST pass for this workgroup's 2048 slots
   const int tid = threadIdx.x;
+  if (cnt.closed()) return;
   const int R = cnt.get();
-  if ((size_t)blockIdx.x * EMIT_CHUNK >= (size_t)R) return;  // (grid sized for the capacity)
+  for_each_unit(units_of(R, EMIT_CHUNK), [&](const int chunk) {
   hist[tid] = 0;
-  const uint32_t c0 = (uint32_t)blockIdx.x * EMIT_CHUNK;
+  const uint32_t c0 = (uint32_t)chunk * EMIT_CHUNK;
   const uint32_t c1 = c0 + EMIT_CHUNK < (uint32_t)R ? c0 + EMIT_CHUNK : (uint32_t)R;
-  const int S = emit_stage(sdesc, chunk_first, (int)blockIdx.x, c1, R, tid, st);
+  const int S = emit_stage(sdesc, chunk_first, chunk, c1, R, tid, st);
   __syncthreads();
   // Each thread owns EIGHT consecutive slots: one bisection for the first, then it walks (row, col) and steps to
   // the next Gaussian when a run ends -- 4x fewer LDS round trips than a search per slot, 32-byte stores.
@@ -1071,6 +1063,7 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, const uint4*
   __syncthreads();
   const uint32_t hc = hist[tid];
   if (hc) atomicAdd(&counts0[(size_t)(c0 / TSORT_TILE) * 256 + tid], hc);
+  });
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1505,11 +1498,12 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps_k_preprocess(K_PREPROCESS, s);
   const size_t stage = (shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0;  // M > 1: SH rows go through LDS
-  // one resident round: 4 workgroups of 4 waves per CU (3 when 50 KB of LDS each hold SH rows) x 256 CUs, the
-  // blocks spread evenly over them.  ~80 VGPRs allow five waves per SIMD, so more workgroups only queue up, and every
-  // workgroup ends with ~770 histogram flush atomics and one same-address count atomic (C3: 2, 3, 4, 8, 12, 16 per CU
-  // = 74, 71, 70, 75, 89, 105 us)
-  static const int wg_per_cu = getenv("GSR_PRE_WG_PER_CU") ? atoi(getenv("GSR_PRE_WG_PER_CU")) : 4;  // experiment knob
+  // one resident round: 3 workgroups of 4 waves per CU x 256 CUs, the blocks spread evenly over them.  The kernel's
+  // time does not depend on the occupancy between 2 and 5 waves per SIMD (C3, one box: 2, 3, 4, 5, 6 per CU = 63, 63,
+  // 64, 67, 70 us; with the arithmetic compiled out it still takes 56 us for its 252 MB: it is bound by the memory
+  // path, not by latency or VALU), and every workgroup ends with ~770 histogram flush atomics and one same-address count
+  // atomic, so fewer and longer-lived workgroups win
+  static const int wg_per_cu = getenv("GSR_PRE_WG_PER_CU") ? atoi(getenv("GSR_PRE_WG_PER_CU")) : 3;  // experiment knob
   const int max_wg = (stage ? 3 : wg_per_cu) * 256, rounds = (nb + max_wg - 1) / max_wg;
   const dim3 grid(rounds ? (nb + rounds - 1) / rounds : 1);
   if (stage)
@@ -1544,10 +1538,10 @@ hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint
   return hipGetLastError();
 }
 
-hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, int capB, uint32_t slot_base, const uint32_t* sat,
+hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, Count capB, uint32_t slot_base, const uint32_t* sat,
                                    uint32_t* chunk_firstB, uint32_t* counts0, unsigned long long* publish,
                                    uint32_t ticket, hipStream_t s) {
-  const size_t ncounts0 = (size_t)((capB + TSORT_TILE - 1) / TSORT_TILE) * 256;
+  const size_t ncounts0 = (size_t)((capB.cap + TSORT_TILE - 1) / TSORT_TILE) * 256;
   ProfScope ps(K_SCAN_OFFSETS, s);
   hipLaunchKernelGGL(k_scan_offsets_far, dim3((fp.P + SCAN_TILE - 1) / SCAN_TILE), dim3(PRE_BLOCK), 0, s, fp, g, capB,
                      slot_base, sat, chunk_firstB, counts0, ncounts0, publish, ticket);
@@ -1559,7 +1553,7 @@ hipError_t launch_emit(const FrameParams& fp, const uint4* sdesc, Count R, uint3
                        bool store_pairs, hipStream_t s) {
   if (R.cap <= 0) return hipSuccess;
   ProfScope ps(K_EMIT, s);
-  const dim3 grid((R.cap + EMIT_CHUNK - 1) / EMIT_CHUNK);
+  const dim3 grid(chain_grid(R, EMIT_CHUNK));
   if (key16 && store_pairs)
     hipLaunchKernelGGL((k_emit<uint16_t, true>), grid, dim3(256), 0, s, fp, sdesc, R, chunk_first,
                        reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_mask0);
@@ -1576,7 +1570,7 @@ hipError_t launch_emit(const FrameParams& fp, const uint4* sdesc, Count R, uint3
 hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_t* vals_out, int nbits0,
                                const uint32_t* counts, const uint32_t* chunk_base, const uint32_t* digit_total,
                                bool arank, hipStream_t s) {
-  const dim3 grid((ef.R.cap + TSORT_TILE - 1) / TSORT_TILE);
+  const dim3 grid(chain_grid(ef.R, TSORT_TILE));
   if (arank)
     hipLaunchKernelGGL(k_emit_scatter<true>, grid, dim3(256), 0, s, ef.fp, ef.sdesc, ef.R, ef.chunk_first, keys_out, vals_out,
                        nbits0, counts, chunk_base, digit_total);

@@ -41,11 +41,13 @@ __global__ __launch_bounds__(256) void k_sort_hist(const K* __restrict__ keys, c
                                                    uint32_t* __restrict__ counts) {
   __shared__ uint32_t hist[256];
   const int tid = threadIdx.x;
+  if (cnt.closed()) return;
   const int n = cnt.get();  // (tiles beyond it leave zero counts: the scans run over the capacity's tiles)
   const uint32_t mask = (1u << nbits) - 1u;
+  for_each_unit(units_of(cnt.cap, TILE), [&](const int tile) {
   hist[tid] = 0;
   __syncthreads();
-  const size_t base = (size_t)blockIdx.x * TILE;
+  const size_t base = (size_t)tile * TILE;
   uint32_t key[TILE / 256];
 #pragma unroll
   for (int s = 0; s < TILE / 256; s++) {
@@ -58,12 +60,14 @@ __global__ __launch_bounds__(256) void k_sort_hist(const K* __restrict__ keys, c
     if (i < (size_t)n) atomicAdd(&hist[(key[s] >> shift) & mask], 1u);
   }
   __syncthreads();
-  counts[(size_t)blockIdx.x * 256 + tid] = hist[tid];
+  counts[(size_t)tile * 256 + tid] = hist[tid];
+  });
 }
 
 // grid = nchunks, block = 256 (thread = digit).
 __global__ __launch_bounds__(256) void k_sort_scan_chunks(uint32_t* __restrict__ counts, int ntiles,
-                                                          uint32_t* __restrict__ chunk_sums) {
+                                                          uint32_t* __restrict__ chunk_sums, const Count gate) {
+  if (gate.closed()) return;
   const int d = threadIdx.x;
   const int t0 = blockIdx.x * SORT_CHUNK;
   uint32_t v[SORT_CHUNK];
@@ -81,7 +85,8 @@ __global__ __launch_bounds__(256) void k_sort_scan_chunks(uint32_t* __restrict__
 
 // grid = 64, block = 256: one wave per digit scans that digit's column of chunk_sums.
 __global__ __launch_bounds__(256) void k_sort_scan_top(uint32_t* __restrict__ chunk_sums, int nchunks,
-                                                       uint32_t* __restrict__ digit_total) {
+                                                       uint32_t* __restrict__ digit_total, const Count gate) {
+  if (gate.closed()) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int d = blockIdx.x * 4 + w;
   uint32_t carry = 0;
@@ -101,7 +106,8 @@ __global__ __launch_bounds__(256) void k_sort_scan_top(uint32_t* __restrict__ ch
 // Beyond that size a column no longer fits a wave's few round trips and the two-level scan above is faster.
 constexpr int SCAN_COLUMNS_MAX = 2048;
 __global__ __launch_bounds__(256) void k_sort_scan_columns(uint32_t* __restrict__ counts, const int ntiles,
-                                                           uint32_t* __restrict__ digit_total) {
+                                                           uint32_t* __restrict__ digit_total, const Count gate) {
+  if (gate.closed()) return;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int d = blockIdx.x * 4 + w;
   uint32_t carry = 0;
@@ -270,21 +276,21 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
     const int shift = nbits * p;
     if (!(p == 0 && first_hist_done)) {  // the emitter already left the first pass's counts in sc.counts
       ProfScope ps(K_SORT_HIST + kb, s);
-      hipLaunchKernelGGL((k_sort_hist<K, TT>), dim3(ntiles), dim3(256), 0, s, kin, cnt, shift, nbits, sc.counts);
+      hipLaunchKernelGGL((k_sort_hist<K, TT>), dim3(chain_grid(cnt, TT)), dim3(256), 0, s, kin, cnt, shift, nbits, sc.counts);
     }
     const bool one_scan = ntiles <= SCAN_COLUMNS_MAX && !two_level_scan;
     const uint32_t* chunk_base = one_scan ? nullptr : sc.chunk_sums;
     if (one_scan) {
       ProfScope ps(K_SORT_SCAN_CHUNKS + kb, s);
-      hipLaunchKernelGGL(k_sort_scan_columns, dim3(64), dim3(256), 0, s, sc.counts, ntiles, sc.digit_base);
+      hipLaunchKernelGGL(k_sort_scan_columns, dim3(64), dim3(256), 0, s, sc.counts, ntiles, sc.digit_base, cnt);
     } else {
       {
         ProfScope ps(K_SORT_SCAN_CHUNKS + kb, s);
-        hipLaunchKernelGGL(k_sort_scan_chunks, dim3(nchunks), dim3(256), 0, s, sc.counts, ntiles, sc.chunk_sums);
+        hipLaunchKernelGGL(k_sort_scan_chunks, dim3(nchunks), dim3(256), 0, s, sc.counts, ntiles, sc.chunk_sums, cnt);
       }
       {
         ProfScope ps(K_SORT_SCAN_TOP + kb, s);
-        hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, sc.chunk_sums, nchunks, sc.digit_base);
+        hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, sc.chunk_sums, nchunks, sc.digit_base, cnt);
       }
     }
     if (p == 0 && ef && sizeof(K) == 2) {  // the emitter generates the pairs inside the first pass
@@ -296,21 +302,21 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
       // last pass of the instance sort: per-key counts instead of the sorted keys (sort_core.hpp, COUNT)
       ProfScope ps(K_SORT_SCATTER + kb, s);
       if (arank)
-        hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT, true>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout,
+        hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT, true>), dim3(chain_grid(cnt, TT)), dim3(64 * NWV), 0, s, kin, vin, kout,
                            vout, cnt, shift, nbits, sc.counts, chunk_base, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr, key_count);
       else
-        hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT, true>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout,
+        hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT, true>), dim3(chain_grid(cnt, TT)), dim3(64 * NWV), 0, s, kin, vin, kout,
                            vout, cnt, shift, nbits, sc.counts, chunk_base, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr, key_count);
     } else {
       ProfScope ps(K_SORT_SCATTER + kb, s);
       if (arank)
-        hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, cnt,
+        hipLaunchKernelGGL((k_sort_scatter<K, false, true, NWV, TT>), dim3(chain_grid(cnt, TT)), dim3(64 * NWV), 0, s, kin, vin, kout, vout, cnt,
                            shift, nbits, sc.counts, chunk_base, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
       else
-        hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT>), dim3(ntiles), dim3(64 * NWV), 0, s, kin, vin, kout, vout, cnt,
+        hipLaunchKernelGGL((k_sort_scatter<K, false, false, NWV, TT>), dim3(chain_grid(cnt, TT)), dim3(64 * NWV), 0, s, kin, vin, kout, vout, cnt,
                            shift, nbits, sc.counts, chunk_base, sc.digit_base, (uint32_t*)nullptr,
                            (uint32_t*)nullptr);
     }
@@ -388,6 +394,7 @@ template <typename K>
 __global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys, const Count cnt, uint2* __restrict__ ranges,
                                                      const uint32_t list_base) {
   constexpr int PER = 16 / (int)sizeof(K);
+  if (cnt.closed()) return;
   const int L = cnt.get();
   const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * PER;
   if (i0 >= (size_t)L) return;
@@ -419,8 +426,9 @@ __global__ __launch_bounds__(256) void k_tile_ranges(const K* __restrict__ keys,
 // Ranges from the per-tile instance counts the last sort pass left in ranges[t].y (ranges[t].x still zero): one
 // workgroup scans them; tiles without instances keep the reference's (0, 0) (its cudaMemset, rasterizer_impl.cu:311).
 __global__ __launch_bounds__(1024) void k_ranges_from_counts(uint2* __restrict__ ranges, const int T,
-                                                             const uint32_t list_base) {
+                                                             const uint32_t list_base, const Count gate) {
   __shared__ uint32_t wsum[16];
+  if (gate.closed()) return;
   __shared__ uint32_t carry_s;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) carry_s = list_base;  // (the far segment of a near/far frame lives behind the near capacity)
@@ -448,9 +456,9 @@ __global__ __launch_bounds__(1024) void k_ranges_from_counts(uint2* __restrict__
   }
 }
 
-hipError_t launch_ranges_from_counts(uint2* ranges, int T, uint32_t list_base, hipStream_t s) {
+hipError_t launch_ranges_from_counts(uint2* ranges, int T, uint32_t list_base, Count gate, hipStream_t s) {
   ProfScope ps(K_TILE_RANGES, s);
-  hipLaunchKernelGGL(k_ranges_from_counts, dim3(1), dim3(1024), 0, s, ranges, T, list_base);
+  hipLaunchKernelGGL(k_ranges_from_counts, dim3(1), dim3(1024), 0, s, ranges, T, list_base, gate);
   return hipGetLastError();
 }
 

@@ -200,7 +200,9 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
                                                       float* __restrict__ out_depth, float* __restrict__ out_acc,
                                                       unsigned long long* __restrict__ done_word,
                                                       unsigned long long* __restrict__ publish, const uint32_t ticket,
-                                                      uint32_t* __restrict__ live_quads_out) {
+                                                      uint32_t* __restrict__ live_quads_out, const AsyncWords aw,
+                                                      const Count gate) {
+  if (PHASE == 2 && gate.closed()) return;  // (asynchronous frame whose near chain finished every quad)
   __shared__ float4 sAll[FW][3][64];  // wave-private images: no barrier in the blending itself
   // PHASE 1 counts the quads it leaves unfinished and the launch's last workgroup hands the total to the host (api.hip:
   // a frame whose far chain was not enqueued is complete iff that total is zero).  Finished waves per workgroup and
@@ -343,6 +345,12 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
           if (publish)
             __hip_atomic_store(publish, ((unsigned long long)ticket << 32) | live, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
+          if (aw.decide) {  // asynchronous frame: open the far chain waiting on the other stream, or release this one
+            const uint32_t d = 2u * aw.seq + (live ? 1u : 0u);
+            __hip_atomic_store(aw.gate_dev, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (live == 0u) __hip_atomic_store(aw.go, aw.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(aw.decide, d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // (after the gate word)
+          }
         }
       }
     }
@@ -788,8 +796,10 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
 // the global-memory variant below walks rows and columns with dependent loads: 54 us).
 template <bool IN_LDS>
 __global__ __launch_bounds__(1024) void k_live_sat(const uint8_t* __restrict__ quad_done, const int gx, const int gy,
-                                                   uint32_t* __restrict__ sat, uint32_t* __restrict__ total_live) {
+                                                   uint32_t* __restrict__ sat, uint32_t* __restrict__ total_live,
+                                                   const Count gate) {
   extern __shared__ uint32_t s_sat[];
+  if (gate.closed()) return;
   uint32_t* const S = IN_LDS ? s_sat : sat;
   const int sw = gx + 1, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (IN_LDS) {
@@ -844,7 +854,17 @@ __global__ __launch_bounds__(1024) void k_live_sat(const uint8_t* __restrict__ q
   if (tid == 0) *total_live = S[gy * sw + gx];
 }
 
-hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, hipStream_t s) {
+__global__ void k_release_go(const Count gate, uint32_t* __restrict__ go, const uint32_t seq) {
+  if (threadIdx.x == 0 && !gate.closed()) __hip_atomic_store(go, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// last launch of an asynchronous frame's far chain: lets the caller's stream go on (if the chain ran; otherwise the
+// near blend has released it long ago)
+hipError_t launch_release_go(Count gate, uint32_t* go, uint32_t seq, hipStream_t s) {
+  hipLaunchKernelGGL(k_release_go, dim3(1), dim3(64), 0, s, gate, go, seq);
+  return hipGetLastError();
+}
+
+hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, Count gate, hipStream_t s) {
   ProfScope ps(K_LIVE_SAT, s);
   const size_t bytes = (size_t)(fp.gx + 1) * (fp.gy + 1) * sizeof(uint32_t);
   if (bytes <= 150 * 1024) {
@@ -852,9 +872,10 @@ hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
     if (attr != hipSuccess) return attr;
     hipLaunchKernelGGL(k_live_sat<true>, dim3(1), dim3(1024), bytes, s, im.quad_done, fp.gx, fp.gy, im.live_sat,
-                       total_live);
+                       total_live, gate);
   } else {
-    hipLaunchKernelGGL(k_live_sat<false>, dim3(1), dim3(1024), 0, s, im.quad_done, fp.gx, fp.gy, im.live_sat, total_live);
+    hipLaunchKernelGGL(k_live_sat<false>, dim3(1), dim3(1024), 0, s, im.quad_done, fp.gx, fp.gy, im.live_sat, total_live,
+                       gate);
   }
   return hipGetLastError();
 }
@@ -862,7 +883,7 @@ hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total
 hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                 float* out_color, float* out_depth, float* out_acc, int phase,
                                 unsigned long long* done_word, unsigned long long* publish, uint32_t ticket,
-                                hipStream_t s) {
+                                AsyncWords aw, Count gate, hipStream_t s) {
   ProfScope ps_k_blend_fwd(K_BLEND_FWD, s);
   // the four quads of a tile share a workgroup slot (they never synchronise): their redundant gathers of the same
   // records coincide in time and hit L1/L2; 1, 2 and 4 waves per workgroup measured within 3 % of each other
@@ -870,7 +891,7 @@ hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState
 #define GSR_LAUNCH_FWD(PH)                                                                                            \
   hipLaunchKernelGGL((k_blend_forward<4, PH>), dim3((quads + 3) / 4), dim3(256), 0, s, fp, im.ranges, im.rangesB,      \
                      b.point_list, g.splats, bg, im.final_T, im.n_contrib, im.quad_last, im.quad_done, out_color,      \
-                     out_depth, out_acc, done_word, publish, ticket, g.total + 13)
+                     out_depth, out_acc, done_word, publish, ticket, g.total + 13, aw, gate)
   if (phase == 1) GSR_LAUNCH_FWD(1);
   else if (phase == 2) GSR_LAUNCH_FWD(2);
   else GSR_LAUNCH_FWD(0);

@@ -248,26 +248,29 @@ __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ 
   constexpr int WTILE = TILE / NW, NSTEP = WTILE / 64;
   __shared__ ScatterLds<K, NW, TILE> L;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (!LB && cnt.closed()) return;
   const int n = cnt.get();
-  if (!LB && (size_t)blockIdx.x * TILE >= (size_t)n) return;  // (grid sized for the capacity: nothing in this tile)
-  int tile = blockIdx.x;
-  if (LB) {
+  auto one_tile = [&](const int tile) {
+    const size_t base = (size_t)tile * TILE + (size_t)w * WTILE;
+    uint32_t key[NSTEP], val[NSTEP];
+#pragma unroll
+    for (int s = 0; s < NSTEP; s++) {
+      const size_t i = base + (size_t)s * 64 + lane;
+      const bool valid = i < (size_t)n;
+      key[s] = valid ? (uint32_t)keys_in[i] : 0u;
+      val[s] = valid ? vals_in[i] : 0u;
+    }
+    scatter_core<K, LB, ARANK, NW, TILE, COUNT>(L, key, val, tile, keys_out, vals_out, n, shift, nbits, counts, chunk_base,
+                                                digit_total, status, key_count);
+  };
+  if (LB) {  // one ticketed tile per workgroup
     __shared__ int s_tile;
     if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
     __syncthreads();
-    tile = s_tile;
+    one_tile(s_tile);
+  } else {   // the tiles that hold pairs, grid stride (gsr_internal.hpp, for_each_unit)
+    for_each_unit(units_of(n, TILE), one_tile);
   }
-  const size_t base = (size_t)tile * TILE + (size_t)w * WTILE;
-  uint32_t key[NSTEP], val[NSTEP];
-#pragma unroll
-  for (int s = 0; s < NSTEP; s++) {
-    const size_t i = base + (size_t)s * 64 + lane;
-    const bool valid = i < (size_t)n;
-    key[s] = valid ? (uint32_t)keys_in[i] : 0u;
-    val[s] = valid ? vals_in[i] : 0u;
-  }
-  scatter_core<K, LB, ARANK, NW, TILE, COUNT>(L, key, val, tile, keys_out, vals_out, n, shift, nbits, counts, chunk_base,
-                                              digit_total, status, key_count);
 }
 
 }  // namespace gsr

@@ -109,18 +109,27 @@ int gsr_near_far(void);
 int gsr_last_near_far(unsigned* near_instances, unsigned* far_instances);
 void gsr_set_near_far_hints(long long near_entries_per_tile, long long far_capacity);
 unsigned long long gsr_near_far_forwards(void);
-/* Far-chain speculation.  When a thread's last two split forwards left no tile live after the near chain
- * (a dense scene: the far chain's launches found nothing to do), its next split forward does not enqueue
- * the far chain: the near chain ends with the count of live tiles in the mailbox and the backward's tile
- * order, and the host reads that word where it reads num_rendered.  Zero: the frame is complete.
- * Otherwise the far chain is enqueued then (one host round trip); results are identical either way.
+/* Far-chain speculation.  When a thread's last two split forwards left no quad unfinished after the near
+ * chain (a dense scene: the far chain's launches found nothing to do), its next split forward is
+ *   - asynchronous, where the device supports stream-side waits (hipStreamWaitValue32; GSR_ASYNC_FAR=0
+ *     switches this off): the far chain is enqueued on a stream of the library's own behind a wait for
+ *     the near blend's decision, each of its kernels gated on "needed", and the caller's stream waits
+ *     for the frame's go word -- stored by the near blend itself when nothing is left to do, by the far
+ *     chain's last kernel otherwise.  gsr_forward returns without waiting for the decision; the far
+ *     segment of the binning blob is sized for every instance behind the near budget;
+ *   - otherwise decided by the host: the count of unfinished quads arrives in the mailbox where
+ *     num_rendered does, and the far chain is enqueued only if it is non-zero (one host round trip).
+ * Results are identical in every variant.  While an asynchronous frame is in flight,
+ * gsr_last_num_rendered / gsr_last_near_far report the near chain's count and add the far chain's once
+ * the frame has got there (they never wait).
  * gsr_set_far_speculation (test / tuning hook, calling thread): 1 = the NEXT split forward speculates,
  * 0 = none does, negative = automatic (and the streak restarts); returns the previous setting.
- * gsr_last_far_skipped: 1 if the calling thread's last forward completed without a far chain. */
+ * gsr_last_far_skipped: 1 if the calling thread's last forward completed without running a far chain. */
 int gsr_set_far_speculation(int mode);
 int gsr_last_far_skipped(void);
 unsigned long long gsr_far_skips(void);       /* process-wide counters */
 unsigned long long gsr_far_skip_misses(void);
+unsigned long long gsr_async_far_frames(void);
 
 /* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:53-88,
  * rasterizer_impl.cu:346-457).  geom/binning/image blobs are the ones the forward
