@@ -6,6 +6,9 @@
 # 3. FETCH_SIZE / WRITE_SIZE in two separate --pmc passes    -> <tag>_pmc_traffic.json   (tools/pmc_summary.py)
 # 4. SQ counters in their own --pmc pass                      -> <tag>_sq_counters.json   (tools/sq_summary.py)
 # Counter passes carry --kernel-trace only (never a sys/hip/hsa trace); python3 comes directly after `--`.
+# They run with GSR_ASYNC_FAR=0: counter collection serialises the dispatches of all queues, and a far chain parked behind
+# a stream-side wait (asynchronous near/far frames) then never sees the near blend it waits for -- the run hangs.  The
+# counters of the kernels themselves do not depend on which stream the far chain was enqueued on.
 set -e -o pipefail
 tag=${1:?tag}
 out=gpurun_out/prof_$tag
@@ -18,6 +21,7 @@ cp "$(find "$out/stats" -name '*kernel_stats.csv' | head -1)" "$out/${tag}_kerne
 echo "[profile_round] stats done"
 python3 bench.py --steps 20 --warmup 5 > "$out/${tag}_bench.json" 2> "$out/bench.err"
 echo "[profile_round] clean bench done"
+export GSR_ASYNC_FAR=0
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline \
     > /dev/null 2> "$out/pmc_fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline \
