@@ -111,16 +111,17 @@ __global__ __launch_bounds__(256) void k_sort_scan_columns(uint32_t* __restrict_
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const int d = blockIdx.x * 4 + w;
   uint32_t carry = 0;
-  for (int c0 = 0; c0 < ntiles; c0 += 512) {
-    uint32_t v[8];
+  for (int c0 = 0; c0 < ntiles; c0 += 1024) {  // (a near chain's 640 tiles: one round trip)
+    uint32_t v[16];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 16; k++) {
       const int t = c0 + 64 * k + lane;
       v[k] = t < ntiles ? counts[(size_t)t * 256 + d] : 0u;
     }
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
+    for (int k = 0; k < 16; k++) {
       const int t = c0 + 64 * k + lane;
+      if (c0 + 64 * k >= ntiles) break;  // (wave-uniform)
       const uint32_t inc = wave_incl_scan(v[k], lane);
       if (t < ntiles) counts[(size_t)t * 256 + d] = carry + inc - v[k];
       carry += __shfl(inc, 63, 64);
@@ -433,12 +434,15 @@ __global__ __launch_bounds__(1024) void k_ranges_from_counts(uint2* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (tid == 0) carry_s = list_base;  // (the far segment of a near/far frame lives behind the near capacity)
   __syncthreads();
-  for (int t0 = 0; t0 < T; t0 += 1024 * 4) {
-    const int i0 = t0 + tid * 4;
-    uint32_t c[4];
+  constexpr int PT = 8;  // tiles per thread: a 1080p frame's 8 160 tiles in one round
+  for (int t0 = 0; t0 < T; t0 += 1024 * PT) {
+    const int i0 = t0 + tid * PT;
+    uint32_t c[PT];
 #pragma unroll
-    for (int k = 0; k < 4; k++) c[k] = i0 + k < T ? ranges[i0 + k].y : 0u;
-    const uint32_t sum = c[0] + c[1] + c[2] + c[3];
+    for (int k = 0; k < PT; k++) c[k] = i0 + k < T ? ranges[i0 + k].y : 0u;
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < PT; k++) sum += c[k];
     const uint32_t inc = wave_incl_scan(sum, lane);
     if (lane == 63) wsum[w] = inc;
     __syncthreads();
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(1024) void k_ranges_from_counts(uint2* __restrict__
     for (int k = 0; k < w; k++) base += wsum[k];
     uint32_t run = base + inc - sum;
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
+    for (int k = 0; k < PT; k++) {
       if (i0 + k < T) ranges[i0 + k] = c[k] ? make_uint2(run, run + c[k]) : make_uint2(0u, 0u);
       run += c[k];
     }

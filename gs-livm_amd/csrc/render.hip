@@ -610,7 +610,14 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
     const uint32_t m = max(max(q.x, q.y), max(q.z, q.w));
     return m < 1023u ? m : 1023u;
   };
-  for (int t = tid; t < T; t += 1024) atomicAdd(&bins[walk(t)], 1u);
+  // (a tile's walk is needed twice, its loads are requested once: up to 8 tiles per thread = a 1080p frame in registers)
+  uint32_t wk[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) wk[k] = tid + 1024 * k < T ? walk(tid + 1024 * k) : 0u;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (tid + 1024 * k < T) atomicAdd(&bins[wk[k]], 1u);
+  for (int t = tid + 8192; t < T; t += 1024) atomicAdd(&bins[walk(t)], 1u);
   __syncthreads();
   const uint32_t v = bins[1023 - tid];  // thread i owns bin 1023 - i: an exclusive scan over i = over longer walks
   uint32_t inc = v;
@@ -625,7 +632,10 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
   for (int k = 0; k < w; k++) base += wtot[k];
   bins[1023 - tid] = base;
   __syncthreads();
-  for (int t = tid; t < T; t += 1024) order[atomicAdd(&bins[walk(t)], 1u)] = (uint32_t)t;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+    if (tid + 1024 * k < T) order[atomicAdd(&bins[wk[k]], 1u)] = (uint32_t)(tid + 1024 * k);
+  for (int t = tid + 8192; t < T; t += 1024) order[atomicAdd(&bins[walk(t)], 1u)] = (uint32_t)t;
 }
 
 template <int TW>  // tiles (= waves) per workgroup; the waves never synchronise

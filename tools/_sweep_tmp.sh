@@ -1,6 +1,3 @@
-for rep in 1 2 3; do python bench.py --workload C5shape --loss photometric --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(' C5shape+photo ms/step %.4f  sum %.4f' % (d['ms_per_step'], d['whole_path']['kernel_ms_per_step']))"; done
-python bench.py --no-cpu-baseline 2>/dev/null | python -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print(' C3 ms/step %.4f  sum %.4f' % (d['ms_per_step'], d['whole_path']['kernel_ms_per_step']))"
+timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/t11.log 2>&1; tail -2 gpurun_out/t11.log
+grep -q " passed" gpurun_out/t11.log || exit 1
+python bench.py --no-cpu-baseline 2>/dev/null > gpurun_out/b6.json; python tools/print_bench.py gpurun_out/b6.json
