@@ -408,9 +408,16 @@ struct Chain {
   uint32_t base;         // first slot / list position of this chain in the frame's slot space (phase 2: capA)
 };
 
+struct DepthOrder {
+  const uint32_t* near_order;  // what the near / whole-frame scan walks: g.order, or the sorted near candidates
+  bool partial;                // partial depth sort: the full order does not exist yet when the far chain starts
+  const uint32_t* ghist;       // k_preprocess's digit counts of all P keys (for that full sort), or null
+};
+
 static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, BinningState& b, const Chain& ch,
-                         ThreadCtx& c, const float* background, float* out_color, float* out_depth, float* out_acc,
-                         int debug, hipStream_t stream, AsyncWords aw = AsyncWords()) {
+                         ThreadCtx& c, const DepthOrder& dord, const float* background, float* out_color,
+                         float* out_depth, float* out_acc, int debug, hipStream_t stream,
+                         AsyncWords aw = AsyncWords()) {
   const Count cnt = ch.cnt;  // (carries the gate of an asynchronous frame's far chain)
   const int tiles = fp.gx * fp.gy;
   const int tile_bits = (int)gsr_higher_msb((uint32_t)tiles);  // the `bit` of rasterizer_impl.cu:295
@@ -423,6 +430,16 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
   uint8_t* inst_flag = b.inst_flag + ch.base;
   uint2* ranges = far ? im.rangesB : im.ranges;
   if (far) {
+    if (dord.partial) {
+      // the far chain walks the far Gaussians in depth order: the full sort a partial depth sort has left out.  It re-uses
+      // the pass tickets and look-back status words the near sort has used (words 1024 .. scan_off of the scratch);
+      // both launches carry this chain's gate
+      Count all = cnt;
+      all.dev = nullptr;
+      all.cap = fp.P;
+      STAGE(launch_clear_words(all, g.dsort.words + 1024, g.dsort.scan_off - 1024, stream));
+      STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, all, dord.ghist, stream));
+    }
     STAGE(launch_live_sat(fp, im, g.total + 9, cnt, stream));  // which tiles did the near chain leave unfinished
     STAGE(launch_scan_offsets_far(fp, g, cnt, ch.base, im.live_sat, chunk_first, b.tsort.counts, c.mailbox_dev + 1,
                                   c.ticket, stream));
@@ -430,7 +447,7 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
   else
     STAGE(launch_scan_offsets(fp, g, cnt, chunk_first, im.ranges, im.rangesB, b.tsort.counts, ch.near_budget,
                               ch.phase == 1 ? c.mailbox_dev + 2 : nullptr, c.ticket, ch.phase == 1 ? c.top_hist : nullptr,
-                              stream));
+                              ch.phase == 1 ? dord.near_order : g.order, ch.phase == 1 && dord.partial, stream));
   STAGE(launch_emit(fp, sdesc, cnt, chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? point_list : b.ivalsB,
                     inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16,
                     /*store_pairs=*/!key16, stream));  // 16-bit keys: the pairs are generated inside the first sort pass
@@ -546,7 +563,6 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
                           projmatrix, cam_pos, g, radii, /*write_cov3D=*/debug != 0, c.done_counter, c.mailbox_dev, c.ticket,
                           ghist_acc, ghist_clear, stream));
   c.top_hist = ghist_acc ? ghist_acc + 3 * 256 : nullptr;  // rows 3 (counts by top byte) and 4 (tile sums) are adjacent
-  STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, P, ghist_acc, stream));
   if (debug) STAGE(launch_point_offsets(fp, g, stream));  // the reference's array, for the views only
 
   static const bool env_sync = getenv("GSR_SYNC_FORWARD") != nullptr;
@@ -581,6 +597,27 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const bool near_far = speculate && near_far_flag().load() && !fp.ref_rects && near_entries > 0 &&
                         budget64 < 0x20000000ull &&
                         (c.near_entries_override >= 0 || (unsigned long long)hint >= 4ull * budget64);  // (hook: always)
+  // Far-chain speculation (see the near/far branch below): after two split frames in a row that left no quad
+  // unfinished (or when the test hook asks) the thread's next split frame expects its far chain to stay idle.
+  const bool speculate_far = near_far && (c.far_skip_override >= 0 ? c.far_skip_override == 1 : c.far_idle_streak >= 2);
+  if (near_far && c.far_skip_override == 1) c.far_skip_override = -1;
+  // Depth order of the Gaussians.  Such a frame needs it for the NEAR candidates only (k_compact_near): they are
+  // compacted into the sort's second buffer pair and sorted there (partial depth sort: at 2 M Gaussians / 1080p some
+  // 50 000 pairs instead of 2 M, 0.11 -> 0.05 ms); the full sort moves into the far chain, for the frames that run it.
+  static const bool env_full_sort = getenv("GSR_FULL_DEPTH_SORT") != nullptr;  // diagnostics / fallback
+  const bool partial_sort = speculate_far && c.top_hist != nullptr && !env_full_sort;
+  const uint32_t* near_order = g.order;
+  if (partial_sort) {
+    STAGE(launch_compact_near(fp, g, c.top_hist, (uint32_t)budget64, g.dkeysB, g.dvalsB, g.total + 15,
+                              g.dsort.ghist_near((size_t)P), stream));
+    STAGE(launch_depth_sort(g.dkeysB, g.dvalsB, g.nkeys2, g.nvals2, g.dsort, Count{g.total + 15, P},
+                            g.dsort.ghist_near((size_t)P), stream));
+    near_order = g.dvalsB;
+  } else {
+    STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, Count{nullptr, P}, ghist_acc, stream));
+  }
+  // what a chain needs to know about the depth order (enqueue_chain)
+  const DepthOrder dord = {near_order, partial_sort, ghist_acc};
   if (!speculate) {
     const int rc = wait_num_rendered(c, stream, &R_host);
     if (rc != GSR_OK) return rc;
@@ -594,7 +631,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
     key = (int)R_host;
     BinningState b = BinningState::carve(bblob, (size_t)key);
-    const int rc2 = enqueue_chain(fp, g, im, b, Chain{0, Count{nullptr, key}, 0xFFFFFFFFu, 0u}, c, background, out_color,
+    const int rc2 = enqueue_chain(fp, g, im, b, Chain{0, Count{nullptr, key}, 0xFFFFFFFFu, 0u}, c, dord, background, out_color,
                                   out_depth, out_acc, debug, stream);
     if (rc2 != GSR_OK) return rc2;
     c.last_near = R_host;
@@ -628,8 +665,6 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       //   * otherwise decided by the host: the near blend publishes the count of unfinished quads to the mailbox and the
       //     far chain is enqueued only if there are any (one host round trip instead of eleven idle launches).
       // The near blend parks the unfinished pixels' state in the same way in every variant: same result.
-      const bool speculate_far = c.far_skip_override >= 0 ? c.far_skip_override == 1 : c.far_idle_streak >= 2;
-      if (c.far_skip_override == 1) c.far_skip_override = -1;
       const bool async_far = speculate_far && async_far_ready(c);
       const bool skip_far = speculate_far && !async_far;
       if (async_far && !capB_forced) capB = std::max(capB, hint > budget ? hint - budget : 0u);
@@ -654,7 +689,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
         aw.gate_dev = reinterpret_cast<uint32_t*>(c.done_counter + 2);
         aw.seq = ++c.async_seq;
       }
-      int rc = enqueue_chain(fp, g, im, b, Chain{1, Count{g.total + 6, (int)capA}, budget, 0u}, c, background, out_color,
+      int rc = enqueue_chain(fp, g, im, b, Chain{1, Count{g.total + 6, (int)capA}, budget, 0u}, c, dord, background, out_color,
                              out_depth, out_acc, debug, stream, aw);
       if (rc != GSR_OK) return rc;
       Chain far_chain{2, Count{g.total + 8, (int)capB}, 0xFFFFFFFFu, capA};
@@ -668,7 +703,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
         // (not timed by the event profiler: the chain waits on its stream for the decision and then, as a rule, only
         // launches and leaves; its kernels run beside the other stream's and would be booked twice)
         t_prof_suppress = true;
-        rc = enqueue_chain(fp, g, im, b, far_chain, c, background, out_color, out_depth, out_acc, debug, c.far_stream);
+        rc = enqueue_chain(fp, g, im, b, far_chain, c, dord, background, out_color, out_depth, out_acc, debug, c.far_stream);
         t_prof_suppress = false;
         if (rc != GSR_OK) return rc;
         HIP_TRY(launch_release_go(far_chain.cnt, c.sig_go, aw.seq, c.far_stream));
@@ -679,7 +714,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       } else if (skip_far) {
         if (launch_tile_order(fp, im, stream) != hipSuccess) return fail(GSR_ERR_HIP, "k_tile_order launch failed");
       } else {
-        rc = enqueue_chain(fp, g, im, b, far_chain, c, background, out_color, out_depth, out_acc, debug, stream);
+        rc = enqueue_chain(fp, g, im, b, far_chain, c, dord, background, out_color, out_depth, out_acc, debug, stream);
         if (rc != GSR_OK) return rc;
       }
       const std::chrono::steady_clock::time_point tw = std::chrono::steady_clock::now();
@@ -705,7 +740,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
         } else {
           if (skip_far) {  // unfinished quads after all
             ++g_far_skip_misses;
-            rc = enqueue_chain(fp, g, im, b, far_chain, c, background, out_color, out_depth, out_acc, debug, stream);
+            rc = enqueue_chain(fp, g, im, b, far_chain, c, dord, background, out_color, out_depth, out_acc, debug, stream);
             if (rc != GSR_OK) return rc;
           }
           if ((rc = wait_num_rendered(c, stream, &R_far, 1)) != GSR_OK) return rc;
@@ -733,7 +768,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
       if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
       BinningState b = BinningState::carve(bblob, (size_t)key);
-      int rc = enqueue_chain(fp, g, im, b, Chain{0, Count{g.total, key}, 0xFFFFFFFFu, 0u}, c, background, out_color,
+      int rc = enqueue_chain(fp, g, im, b, Chain{0, Count{g.total, key}, 0xFFFFFFFFu, 0u}, c, dord, background, out_color,
                              out_depth, out_acc, debug, stream);
       if (rc != GSR_OK) return rc;
       const std::chrono::steady_clock::time_point tw = std::chrono::steady_clock::now();
@@ -761,7 +796,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
       if (!bblob) return fail(GSR_ERR_ALLOC, "binning allocator returned NULL");
       BinningState b = BinningState::carve(bblob, (size_t)key);
-      const int rc = enqueue_chain(fp, g, im, b, Chain{0, Count{nullptr, key}, 0xFFFFFFFFu, 0u}, c, background, out_color,
+      const int rc = enqueue_chain(fp, g, im, b, Chain{0, Count{nullptr, key}, 0xFFFFFFFFu, 0u}, c, dord, background, out_color,
                                    out_depth, out_acc, debug, stream);
       if (rc != GSR_OK) return rc;
       c.last_was_near_far = false;

@@ -78,8 +78,10 @@ struct DepthSortScratch {
   size_t nwords;
   size_t scan_off;   // word offset of the scan's status array
   size_t scanB_off;  // ... of the second-phase scan's (k_scan_offsets_far)
+  size_t scanC_off;  // ... of the near-candidate compaction's (k_compact_near), followed by its [4][256] digit counts
   __host__ __device__ uint32_t* ghist() const { return words; }           // [4][256]
-  __host__ __device__ uint32_t* tickets() const { return words + 1024; }  // [0..3] sort passes, [4] scan, [5] far scan
+  __host__ __device__ uint32_t* tickets() const { return words + 1024; }  // [0..3] sort passes, [4] scan, [5] far scan,
+                                                                          // [6] compaction, [8..11] near sort passes
   __host__ __device__ uint32_t* status(int pass, int ntiles) const {      // [4][ntiles][256]
     return words + 1088 + (size_t)pass * ntiles * 256;
   }
@@ -89,12 +91,19 @@ struct DepthSortScratch {
   __host__ __device__ unsigned long long* scanB_status() const {          // [ceil(n / SCAN_TILE)]
     return reinterpret_cast<unsigned long long*>(words + scanB_off);
   }
+  __host__ __device__ unsigned long long* scanC_status() const {          // [ceil(n / SCAN_TILE)]
+    return reinterpret_cast<unsigned long long*>(words + scanC_off);
+  }
+  __host__ __device__ uint32_t* ghist_near(size_t n) const {              // [4][256]
+    return words + scanC_off + 2 * ((n + SCAN_TILE - 1) / SCAN_TILE);
+  }
   static void carve(Carver& c, size_t n, DepthSortScratch& s) {
     const size_t ntiles = (n + depth_sort_tile(n) - 1) / depth_sort_tile(n);
     const size_t nscan = (n + SCAN_TILE - 1) / SCAN_TILE;
     s.scan_off = 1088 + 4 * ntiles * 256;  // even: the 64-bit status words are 8-byte aligned
     s.scanB_off = s.scan_off + 2 * nscan;
-    s.nwords = s.scanB_off + 2 * nscan;
+    s.scanC_off = s.scanB_off + 2 * nscan;
+    s.nwords = s.scanC_off + 2 * nscan + 1024;
     s.words = c.take<uint32_t>(s.nwords);
   }
 };
@@ -119,6 +128,8 @@ struct GeomState {
   uint32_t* dkeysA;         // [P] depth-sort ping-pong buffers
   uint32_t* dkeysB;
   uint32_t* dvalsB;
+  uint32_t* nkeys2;         // [P] second ping-pong pair of the NEAR sort (partial depth sort, api.hip): the near candidates
+  uint32_t* nvals2;         //     are compacted into (dkeysB, dvalsB) and sorted between that pair and this one
   uint4* sdesc;             // [P+1] the emitters' descriptor of order[i], ONE 16-byte load each:
                             //   x = first instance slot (exclusive scan in depth order; sdesc[P].x = R),
                             //   y = Gaussian id, z = packed tile rect x0 | y0 << 10 | width << 20,
@@ -142,6 +153,8 @@ struct GeomState {
     g.dkeysA = c.take<uint32_t>(P);
     g.dkeysB = c.take<uint32_t>(P);
     g.dvalsB = c.take<uint32_t>(P);
+    g.nkeys2 = c.take<uint32_t>(P);
+    g.nvals2 = c.take<uint32_t>(P);
     g.sdesc = c.take<uint4>(P + 1);
     g.sdescB = c.take<uint4>(P + 1);
     g.touched = c.take<uint8_t>(P);
@@ -281,9 +294,19 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
                              unsigned long long* publish, uint32_t ticket, uint32_t* ghist_acc, uint32_t* ghist_clear,
                              hipStream_t s);
 hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t s);
+// (order: the depth-sorted ids the scan walks -- g.order, or the sorted near candidates of a partial depth sort, of which
+// only the first "near limit" entries exist)
 hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint2* ranges,
                                uint2* rangesB, uint32_t* counts0, uint32_t near_budget,
-                               unsigned long long* publish_near, uint32_t ticket, const uint32_t* top_hist, hipStream_t s);
+                               unsigned long long* publish_near, uint32_t ticket, const uint32_t* top_hist,
+                               const uint32_t* order, bool order_is_near_list, hipStream_t s);
+// Partial depth sort: the near candidates (depth keys whose top byte lies in the groups the near budget can reach,
+// from top_hist) are compacted, in id order, into (keys_out, vals_out); their number goes to *n_out, their digit
+// counts to ghist_near.
+hipError_t launch_compact_near(const FrameParams& fp, GeomState g, const uint32_t* top_hist, uint32_t near_budget,
+                               uint32_t* keys_out, uint32_t* vals_out, uint32_t* n_out, uint32_t* ghist_near,
+                               hipStream_t s);
+hipError_t launch_clear_words(Count gate, uint32_t* words, size_t n, hipStream_t s);
 hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, Count capB, uint32_t slot_base, const uint32_t* sat,
                                    uint32_t* chunk_firstB, uint32_t* counts0, unsigned long long* publish,
                                    uint32_t ticket, hipStream_t s);
@@ -308,8 +331,11 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
                              Count n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
                              bool first_hist_done, const EmitFusion* fused_first_pass, uint32_t* key_count,
                              hipStream_t s);
+// (n.dev != nullptr: the pair count is read on the device -- the near sort of a partial depth sort, whose tile size is
+// that of a sort of n.cap pairs so that both use the scratch alike; n.gate: the gated full sort of an asynchronous
+// frame's far chain)
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
-                             int n, const uint32_t* ghist, hipStream_t s);
+                             Count n, const uint32_t* ghist, hipStream_t s);
 hipError_t launch_ranges_from_counts(uint2* ranges, int T, uint32_t list_base, Count gate, hipStream_t s);
 hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t* point_list, const float4* splats,
                                       uint32_t* violations, hipStream_t s);

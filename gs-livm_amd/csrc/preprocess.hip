@@ -578,6 +578,127 @@ __global__ __launch_bounds__(1024) void k_point_offsets(const int P, const uint2
 // ------------------------------------------------------------------------------------------------
 constexpr unsigned long long SC_GLOBAL = 2ull << 32, SC_LOCAL = 1ull << 32;
 
+// How far into the depth order can the near budget of a near/far frame reach?  k_preprocess left, per TOP BYTE of the
+// depth keys, the number of Gaussians (top_hist[0..255]) and their tile counts (top_hist[256..511]); lanes own four
+// consecutive byte values.  The budget falls into the first group at which the running tile count reaches it: `limit` =
+// the Gaussians up to and including that group (0xFFFFFFFF: the budget is never reached), `top_end` = the first top-byte
+// value behind it.  One wave; shared by k_scan_offsets and k_compact_near so that both draw the same line.
+__device__ __forceinline__ void wave_near_limit(const uint32_t* __restrict__ top_hist, const uint32_t budget, const int lane,
+                                                uint32_t& limit, uint32_t& top_end) {
+  uint32_t cn = 0, sl = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { cn += top_hist[4 * lane + q]; sl += top_hist[256 + 4 * lane + q]; }
+  const uint32_t cn_inc = wave_incl_scan_u32(cn, lane), sl_inc = wave_incl_scan_u32(sl, lane);
+  const uint64_t m = __ballot(sl_inc >= budget);
+  limit = 0xFFFFFFFFu;
+  top_end = 256u;
+  if (m) {
+    const int L = __builtin_ctzll(m);
+    limit = __shfl(cn_inc, L, 64);
+    top_end = 4u * (uint32_t)(L + 1);
+  }
+}
+
+// Partial depth sort (api.hip).  A near/far frame whose far chain is expected to stay idle needs the depth order of
+// the NEAR candidates only -- at 2 M Gaussians / 1080p some 50 000 of them -- so instead of sorting all P (key, id)
+// pairs (4 passes over 2 M pairs: 0.11 ms) the candidates are compacted here, in id order (a stable sort of them
+// then yields exactly the first `limit` entries of the full depth order), and only they are sorted; the full sort is
+// left to the far chain, should it run.  One launch: decoupled look-back over tiles of 16 384 keys (64 per thread: a
+// quarter of k_scan_offsets' chain length -- 27 -> .. us at 2 M), digit counts of the candidates by LDS atomics for the
+// near sort's four passes.
+constexpr int COMPACT_ITEMS = 64, COMPACT_TILE = PRE_BLOCK * COMPACT_ITEMS;
+__global__ __launch_bounds__(PRE_BLOCK) void k_compact_near(const int P, const uint32_t* __restrict__ keys,
+                                                            const uint32_t* __restrict__ top_hist, const uint32_t budget,
+                                                            uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
+                                                            uint32_t* __restrict__ n_out, uint32_t* __restrict__ ghist_near,
+                                                            unsigned long long* __restrict__ st, uint32_t* __restrict__ ticket) {
+  __shared__ uint32_t wtot[PRE_BLOCK / 64];
+  __shared__ uint32_t s_tile, s_prefix, s_top_end;
+  __shared__ uint32_t dh[4][256];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#pragma unroll
+  for (int k = 0; k < 4; k++) dh[k][tid] = 0u;
+  if (tid == 0) s_tile = atomicAdd(ticket, 1u);  // every lower tile is already running
+  if (w == 0) {
+    uint32_t limit, top_end;
+    wave_near_limit(top_hist, budget, lane, limit, top_end);
+    if (lane == 0) s_top_end = top_end;
+  }
+  __syncthreads();
+  const uint32_t tile = s_tile, top_end = s_top_end;
+  // a wave owns COMPACT_ITEMS x 64 consecutive keys and takes them 64 at a time, lane = consecutive key: coalesced loads,
+  // and a candidate's rank among its wave's is a ballot and a popcount of the lower lanes (stable by construction)
+  const int wbase = (int)(tile * COMPACT_TILE) + w * (COMPACT_ITEMS * 64);
+  uint32_t key[COMPACT_ITEMS];
+#pragma unroll
+  for (int r = 0; r < COMPACT_ITEMS; r++) {
+    const int i = wbase + 64 * r + lane;
+    key[r] = i < P ? keys[i] : 0xFFFFFFFFu;
+  }
+  auto is_near = [&](const int r) { return wbase + 64 * r + lane < P && (key[r] >> 24) < top_end; };
+  uint32_t wcount = 0;  // wave-uniform
+#pragma unroll
+  for (int r = 0; r < COMPACT_ITEMS; r++) wcount += (uint32_t)__popcll(__ballot(is_near(r)));
+  if (lane == 0) wtot[w] = wcount;
+  __syncthreads();
+  const uint32_t agg = wtot[0] + wtot[1] + wtot[2] + wtot[3];
+  if (w == 0) {
+    uint32_t prefix = 0;
+    if (tile == 0) {
+      if (lane == 0) __hip_atomic_store(st, SC_GLOBAL | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (lane == 0) __hip_atomic_store(st + tile, SC_LOCAL | agg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      int base = (int)tile - 1;  // lane L inspects tile base - L; beyond tile 0 counts as a known prefix of 0
+      for (;;) {
+        const int t = base - lane;
+        const unsigned long long v =
+            t >= 0 ? __hip_atomic_load(st + t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : SC_GLOBAL;
+        const uint32_t flag = (uint32_t)(v >> 32);
+        const uint64_t mg = __ballot(flag == 2u), mn = __ballot(flag == 0u);
+        const int fg = mg ? __builtin_ctzll(mg) : 64;
+        const uint64_t nearer = fg == 64 ? ~0ull : ((1ull << fg) - 1ull);
+        if (mn & nearer) {  // a nearer tile has not published yet
+          __builtin_amdgcn_s_sleep(1);
+          continue;
+        }
+        prefix += wave_sum_u32(lane <= fg ? (uint32_t)v : 0u);
+        if (fg < 64) break;
+        base -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(st + tile, SC_GLOBAL | (unsigned long long)(prefix + agg), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) s_prefix = prefix;
+  }
+  __syncthreads();
+  if (tile == gridDim.x - 1u && tid == 0) *n_out = s_prefix + agg;  // the candidates of the whole frame
+  if (agg == 0u) return;  // (workgroup-uniform: nothing to write or count)
+  uint32_t pos = s_prefix;
+  for (int k = 0; k < w; k++) pos += wtot[k];
+  if (wcount) {
+#pragma unroll
+    for (int r = 0; r < COMPACT_ITEMS; r++) {
+      const bool take = is_near(r);
+      const uint64_t m = __ballot(take);
+      if (take) {
+        const uint32_t p = pos + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        keys_out[p] = key[r];
+        vals_out[p] = (uint32_t)(wbase + 64 * r + lane);  // (the id: k_preprocess numbers the pairs 0 .. P-1)
+#pragma unroll
+        for (int d = 0; d < 4; d++) atomicAdd(&dh[d][(key[r] >> (8 * d)) & 255u], 1u);
+      }
+      pos += (uint32_t)__popcll(m);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int d = 0; d < 4; d++) {
+    const uint32_t c = dh[d][tid];
+    if (c) (void)__hip_atomic_fetch_add(ghist_near + d * 256 + tid, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
 // `budget` < 0xFFFFFFFF (near/far frames, api.hip): only the NEAR Gaussians -- those whose first slot lies below the
 // budget -- get descriptors, slots and chunk entries; the Gaussian in whose run the budget falls ends the near phase:
 // it publishes the phase's instance count (total[6]) and the depth-order index of the first far Gaussian (total[7]),
@@ -590,7 +711,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
                                                             const uint32_t budget,
                                                             unsigned long long* __restrict__ publish_near,
                                                             const uint32_t ticket,
-                                                            const uint32_t* __restrict__ top_hist) {
+                                                            const uint32_t* __restrict__ top_hist,
+                                                            const uint32_t* __restrict__ order,
+                                                            const bool order_is_near_list) {
   __shared__ uint32_t wtot[PRE_BLOCK / 64];
   __shared__ uint32_t s_tile, s_prefix, s_limit;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -619,15 +742,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
     // the number of Gaussians (top_hist[0..255]) and their tile counts (top_hist[256..511]): the budget falls into the
     // first byte value at which the running tile count reaches it, so no Gaussian beyond that value's last index is
     // needed and the scan tiles behind it leave without touching memory (at 2 M Gaussians / 1080p: 13 of 489 tiles stay).
-    uint32_t limit = 0xFFFFFFFFu;
-    if (split && top_hist) {
-      uint32_t cn = 0, sl = 0;
-#pragma unroll
-      for (int q = 0; q < 4; q++) { cn += top_hist[4 * lane + q]; sl += top_hist[256 + 4 * lane + q]; }
-      const uint32_t cn_inc = wave_incl_scan_u32(cn, lane), sl_inc = wave_incl_scan_u32(sl, lane);
-      const uint64_t m = __ballot(sl_inc >= budget);  // lanes own four consecutive byte values: group granularity
-      if (m) limit = __shfl(cn_inc, __builtin_ctzll(m), 64);
-    }
+    uint32_t limit = 0xFFFFFFFFu, top_end = 256u;
+    if (split && top_hist) wave_near_limit(top_hist, budget, lane, limit, top_end);  // (group granularity)
     if (lane == 0) s_limit = limit;
   }
   __syncthreads();
@@ -644,15 +760,17 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
   }
   const int i0 = (int)(tile * SCAN_TILE) + tid * SCAN_ITEMS;
   uint32_t id[SCAN_ITEMS], n[SCAN_ITEMS], rect[SCAN_ITEMS];
-  if (i0 + SCAN_ITEMS <= fp.P) {
+  // (`order` is the full depth order, or -- partial depth sort -- the sorted near candidates: its first `limit` entries)
+  const int nvalid = order_is_near_list && s_limit < (uint32_t)fp.P ? (int)s_limit : fp.P;
+  if (i0 + SCAN_ITEMS <= nvalid) {
 #pragma unroll
     for (int q = 0; q < SCAN_ITEMS / 4; q++) {
-      const uint4 o = *reinterpret_cast<const uint4*>(g.order + i0 + 4 * q);
+      const uint4 o = *reinterpret_cast<const uint4*>(order + i0 + 4 * q);
       id[4 * q] = o.x; id[4 * q + 1] = o.y; id[4 * q + 2] = o.z; id[4 * q + 3] = o.w;
     }
   } else {
 #pragma unroll
-    for (int k = 0; k < SCAN_ITEMS; k++) id[k] = i0 + k < fp.P ? g.order[i0 + k] : 0xFFFFFFFFu;
+    for (int k = 0; k < SCAN_ITEMS; k++) id[k] = i0 + k < nvalid ? order[i0 + k] : 0xFFFFFFFFu;
   }
   uint32_t sum = 0;
 #pragma unroll
@@ -1484,7 +1602,10 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float* 
 // bins with global atomics, which a one-block workgroup cannot hide (500 k Gaussians: 29 -> 51 us, against 10 us
 // for the sort's own histogram pass)
 bool preprocess_counts_depth_digits(const FrameParams& fp, const float* shs, const float* colors_precomp) {
-  if (fp.P <= (1 << 20)) return false;
+  // (GSR_PRE_HIST_MIN_P: tests run the paths that hang on these histograms -- the near limit, the partial depth sort --
+  // on small scenes)
+  static const long min_p = getenv("GSR_PRE_HIST_MIN_P") ? atol(getenv("GSR_PRE_HIST_MIN_P")) : (1 << 20);
+  if (fp.P <= min_p) return false;
   return !((shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0);
 }
 
@@ -1530,11 +1651,23 @@ hipError_t launch_point_offsets(const FrameParams& fp, GeomState g, hipStream_t 
 
 hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint32_t* chunk_first, uint2* ranges,
                                uint2* rangesB, uint32_t* counts0, uint32_t near_budget,
-                               unsigned long long* publish_near, uint32_t ticket, const uint32_t* top_hist, hipStream_t s) {
+                               unsigned long long* publish_near, uint32_t ticket, const uint32_t* top_hist,
+                               const uint32_t* order, bool order_is_near_list, hipStream_t s) {
   const size_t ncounts0 = (size_t)((R.cap + TSORT_TILE - 1) / TSORT_TILE) * 256;
   ProfScope ps(K_SCAN_OFFSETS, s);
   hipLaunchKernelGGL(k_scan_offsets, dim3((fp.P + SCAN_TILE - 1) / SCAN_TILE), dim3(PRE_BLOCK), 0, s, fp, g, R,
-                     chunk_first, ranges, rangesB, counts0, ncounts0, near_budget, publish_near, ticket, top_hist);
+                     chunk_first, ranges, rangesB, counts0, ncounts0, near_budget, publish_near, ticket, top_hist, order,
+                     order_is_near_list);
+  return hipGetLastError();
+}
+
+hipError_t launch_compact_near(const FrameParams& fp, GeomState g, const uint32_t* top_hist, uint32_t near_budget,
+                               uint32_t* keys_out, uint32_t* vals_out, uint32_t* n_out, uint32_t* ghist_near,
+                               hipStream_t s) {
+  ProfScope ps(K_DSORT_HIST, s);  // (booked with the depth sort: it takes the place of the digit histogram pass)
+  hipLaunchKernelGGL(k_compact_near, dim3((fp.P + COMPACT_TILE - 1) / COMPACT_TILE), dim3(PRE_BLOCK), 0, s, fp.P, g.dkeysA,
+                     top_hist, near_budget, keys_out, vals_out, n_out, ghist_near, g.dsort.scanC_status(),
+                     g.dsort.tickets() + 6);
   return hipGetLastError();
 }
 

@@ -248,7 +248,7 @@ __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ 
   constexpr int WTILE = TILE / NW, NSTEP = WTILE / 64;
   __shared__ ScatterLds<K, NW, TILE> L;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  if (!LB && cnt.closed()) return;
+  if (cnt.closed()) return;
   const int n = cnt.get();
   auto one_tile = [&](const int tile) {
     const size_t base = (size_t)tile * TILE + (size_t)w * WTILE;
@@ -267,7 +267,9 @@ __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ 
     __shared__ int s_tile;
     if (tid == 0) s_tile = (int)atomicAdd(ticket, 1u);
     __syncthreads();
-    one_tile(s_tile);
+    // (a grid sized for a capacity -- the near sort of a partial depth sort: tiles beyond the pairs have nothing to
+    // do and nobody looks back at them)
+    if ((size_t)s_tile * TILE < (size_t)n) one_tile(s_tile);
   } else {   // the tiles that hold pairs, grid stride (gsr_internal.hpp, for_each_unit)
     for_each_unit(units_of(n, TILE), one_tile);
   }

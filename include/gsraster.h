@@ -119,6 +119,10 @@ unsigned long long gsr_near_far_forwards(void);
  *     segment of the binning blob is sized for every instance behind the near budget;
  *   - otherwise decided by the host: the count of unfinished quads arrives in the mailbox where
  *     num_rendered does, and the far chain is enqueued only if it is non-zero (one host round trip).
+ * Such a frame also sorts only its NEAR candidates by depth up front (partial depth sort: the Gaussians whose depth key
+ * lies in the top-byte groups the near budget can reach); the sort of all P Gaussians moves into the far chain
+ * (GSR_FULL_DEPTH_SORT=1: always up front).  gsr_geometry_view.depth_order is the full order only in frames whose far
+ * chain ran or that sorted everything up front.
  * Results are identical in every variant.  While an asynchronous frame is in flight,
  * gsr_last_num_rendered / gsr_last_near_far report the near chain's count and add the far chain's once
  * the frame has got there (they never wait).

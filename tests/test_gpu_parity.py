@@ -376,22 +376,30 @@ def test_near_far_frames_equal_one_chain_frames(gpu_device):
         assert st["async_far_frames"] >= 4, st
 
 
-def test_far_speculation_decided_by_the_host(gpu_device):
-    """GSR_ASYNC_FAR=0 (read once per process: child process): without stream-side waits the near blend's count of
-    unfinished quads goes to the host mailbox and the host enqueues the far chain only if it is non-zero -- the same
-    hit / miss / redo / automatic cases as above through that path."""
+@pytest.mark.parametrize("env", [dict(GSR_ASYNC_FAR="0"), dict(GSR_PRE_HIST_MIN_P="0"),
+                                 dict(GSR_ASYNC_FAR="0", GSR_PRE_HIST_MIN_P="0")],
+                         ids=["host-decided", "partial-sort", "host-decided+partial-sort"])
+def test_far_speculation_variants(env, gpu_device):
+    """The same hit / miss / redo / automatic cases as above through the other paths of the far-chain speculation, each
+    chosen by a knob that is read once per process (child process):
+    GSR_ASYNC_FAR=0 -- without stream-side waits the near blend's count of unfinished quads goes to the host mailbox and
+    the host enqueues the far chain only if it is non-zero;
+    GSR_PRE_HIST_MIN_P=0 -- k_preprocess counts the depth keys' digits on these small scenes too (as it does from 1 M
+    Gaussians), so the frames that expect an idle far chain take the PARTIAL depth sort: near candidates compacted and
+    sorted on their own, the full sort left to the far chain -- which runs it in the miss cases here."""
     import subprocess
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
-    code = ("import sys\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+    code = ("import os, sys\nsys.path.insert(0, %r); sys.path.insert(0, %r)\n"
             "import torch, gs_livm_amd as G\nimport test_gpu_parity as T\n"
             "T.test_near_far_frames_equal_one_chain_frames(torch.device('cuda:0'))\n"
             "s = G.speculation_stats()\n"
-            "assert s['async_far_frames'] == 0 and s['far_skips'] > 0 and s['far_skip_misses'] > 0, s\n"
-            "print('host-decided ok')\n") % (os.path.dirname(here), here)
-    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, GSR_ASYNC_FAR="0"), capture_output=True,
-                         text=True, timeout=600)
-    assert out.returncode == 0 and "host-decided ok" in out.stdout, (out.stdout + out.stderr)[-3000:]
+            "assert s['far_skips'] > 0 and s['far_skip_misses'] > 0, s\n"
+            "assert (s['async_far_frames'] == 0) == (os.environ.get('GSR_ASYNC_FAR') == '0'), s\n"
+            "print('variant ok')\n") % (os.path.dirname(here), here)
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env), capture_output=True, text=True,
+                         timeout=600)
+    assert out.returncode == 0 and "variant ok" in out.stdout, (out.stdout + out.stderr)[-3000:]
 
 
 def test_c3_near_far(c3, gpu_device):
