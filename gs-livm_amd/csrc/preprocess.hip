@@ -580,9 +580,9 @@ constexpr unsigned long long SC_GLOBAL = 2ull << 32, SC_LOCAL = 1ull << 32;
 
 // How far into the depth order can the near budget of a near/far frame reach?  k_preprocess left, per TOP BYTE of the
 // depth keys, the number of Gaussians (top_hist[0..255]) and their tile counts (top_hist[256..511]); lanes own four
-// consecutive byte values.  The budget falls into the first group at which the running tile count reaches it: `limit` =
-// the Gaussians up to and including that group (0xFFFFFFFF: the budget is never reached), `top_end` = the first top-byte
-// value behind it.  One wave; shared by k_scan_offsets and k_compact_near so that both draw the same line.
+// consecutive byte values.  The budget falls into the first byte value at which the running tile count reaches it:
+// `limit` = the Gaussians up to and including that value (0xFFFFFFFF: the budget is never reached), `top_end` = the
+// first top-byte value behind it.  One wave; shared by k_scan_offsets and k_compact_near so that both draw the same line.
 __device__ __forceinline__ void wave_near_limit(const uint32_t* __restrict__ top_hist, const uint32_t budget, const int lane,
                                                 uint32_t& limit, uint32_t& top_end) {
   uint32_t cn = 0, sl = 0;
@@ -590,12 +590,21 @@ __device__ __forceinline__ void wave_near_limit(const uint32_t* __restrict__ top
   for (int q = 0; q < 4; q++) { cn += top_hist[4 * lane + q]; sl += top_hist[256 + 4 * lane + q]; }
   const uint32_t cn_inc = wave_incl_scan_u32(cn, lane), sl_inc = wave_incl_scan_u32(sl, lane);
   const uint64_t m = __ballot(sl_inc >= budget);
+  // inside the lane's four values: the first one at which the running tile count reaches the budget (one top-byte value
+  // = a factor of four in depth; the line is drawn behind it)
+  uint32_t c = cn_inc - cn, t = sl_inc - sl, my_limit = 0xFFFFFFFFu, my_end = 256u;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    c += top_hist[4 * lane + q];
+    t += top_hist[256 + 4 * lane + q];
+    if (t >= budget && my_end == 256u) { my_limit = c; my_end = (uint32_t)(4 * lane + q + 1); }
+  }
   limit = 0xFFFFFFFFu;
   top_end = 256u;
   if (m) {
     const int L = __builtin_ctzll(m);
-    limit = __shfl(cn_inc, L, 64);
-    top_end = 4u * (uint32_t)(L + 1);
+    limit = __shfl(my_limit, L, 64);
+    top_end = __shfl(my_end, L, 64);
   }
 }
 
@@ -743,7 +752,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_scan_offsets(const FrameParams fp
     // first byte value at which the running tile count reaches it, so no Gaussian beyond that value's last index is
     // needed and the scan tiles behind it leave without touching memory (at 2 M Gaussians / 1080p: 13 of 489 tiles stay).
     uint32_t limit = 0xFFFFFFFFu, top_end = 256u;
-    if (split && top_hist) wave_near_limit(top_hist, budget, lane, limit, top_end);  // (group granularity)
+    if (split && top_hist) wave_near_limit(top_hist, budget, lane, limit, top_end);  // (top-byte granularity)
     if (lane == 0) s_limit = limit;
   }
   __syncthreads();
