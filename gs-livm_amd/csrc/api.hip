@@ -218,6 +218,9 @@ struct ThreadCtx {
   uint32_t* sig_go = nullptr;                 // seq once the frame is complete
   uint32_t async_seq = 0;
   int async_state = 0;                        // 0 not probed, 1 usable, -1 unavailable
+  bool near_count_pending = false;            // the last forward ran a partial depth sort: its candidate count is in the
+  uint32_t near_count_ticket = 0;             // mailbox (word 4) -- when it is most of the scene, sort everything again
+  bool near_list_too_long = false;
   bool lazy_pending = false;                  // the last forward returned before its far-chain decision was known
   uint32_t lazy_ticket = 0, lazy_near = 0;
   const uint32_t* top_hist = nullptr;         // this forward's [count | tile sum] by top key byte (k_preprocess), or null
@@ -544,6 +547,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   ThreadCtx& c = g_ctx;
   lazy_resolve(c);  // (what the thread's previous asynchronous frame left open, if the mailbox has it by now)
   c.lazy_pending = false;
+  if (c.near_count_pending) {  // (likewise the previous partial depth sort's candidate count)
+    uint32_t nn = 0;
+    if (peek_word(c, 4, c.near_count_ticket, &nn)) c.near_list_too_long = (unsigned long long)nn * 3ull > (unsigned long long)P;
+    c.near_count_pending = false;
+  }
   {
     const int rc = ctx_prepare(c, stream);
     if (rc != GSR_OK) return rc;
@@ -600,16 +608,23 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   // Far-chain speculation (see the near/far branch below): after two split frames in a row that left no quad
   // unfinished (or when the test hook asks) the thread's next split frame expects its far chain to stay idle.
   const bool speculate_far = near_far && (c.far_skip_override >= 0 ? c.far_skip_override == 1 : c.far_idle_streak >= 2);
-  if (near_far && c.far_skip_override == 1) c.far_skip_override = -1;
+  const bool speculation_forced = near_far && c.far_skip_override == 1;  // (test hook: also overrides the guard below)
+  if (speculation_forced) c.far_skip_override = -1;
   // Depth order of the Gaussians.  Such a frame needs it for the NEAR candidates only (k_compact_near): they are
   // compacted into the sort's second buffer pair and sorted there (partial depth sort: at 2 M Gaussians / 1080p some
   // 50 000 pairs instead of 2 M, 0.11 -> 0.05 ms); the full sort moves into the far chain, for the frames that run it.
   static const bool env_full_sort = getenv("GSR_FULL_DEPTH_SORT") != nullptr;  // diagnostics / fallback
-  const bool partial_sort = speculate_far && c.top_hist != nullptr && !env_full_sort;
+  // (not while the candidates are more than a third of the scene -- the line is drawn at top-byte granularity, a factor
+  // of four in depth: the last partial sort's count says so; every 64th frame tries again)
+  if (c.near_list_too_long && (c.ticket & 63u) == 0u) c.near_list_too_long = false;
+  const bool partial_sort = speculate_far && c.top_hist != nullptr && !env_full_sort &&
+                            (!c.near_list_too_long || speculation_forced);
   const uint32_t* near_order = g.order;
   if (partial_sort) {
     STAGE(launch_compact_near(fp, g, c.top_hist, (uint32_t)budget64, g.dkeysB, g.dvalsB, g.total + 15,
-                              g.dsort.ghist_near((size_t)P), stream));
+                              g.dsort.ghist_near((size_t)P), c.mailbox_dev + 4, c.ticket, stream));
+    c.near_count_pending = true;
+    c.near_count_ticket = c.ticket;
     STAGE(launch_depth_sort(g.dkeysB, g.dvalsB, g.nkeys2, g.nvals2, g.dsort, Count{g.total + 15, P},
                             g.dsort.ghist_near((size_t)P), stream));
     near_order = g.dvalsB;

@@ -305,7 +305,7 @@ hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint
 // counts to ghist_near.
 hipError_t launch_compact_near(const FrameParams& fp, GeomState g, const uint32_t* top_hist, uint32_t near_budget,
                                uint32_t* keys_out, uint32_t* vals_out, uint32_t* n_out, uint32_t* ghist_near,
-                               hipStream_t s);
+                               unsigned long long* publish, uint32_t ticket, hipStream_t s);
 hipError_t launch_clear_words(Count gate, uint32_t* words, size_t n, hipStream_t s);
 hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, Count capB, uint32_t slot_base, const uint32_t* sat,
                                    uint32_t* chunk_firstB, uint32_t* counts0, unsigned long long* publish,

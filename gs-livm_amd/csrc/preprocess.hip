@@ -620,7 +620,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_compact_near(const int P, const u
                                                             const uint32_t* __restrict__ top_hist, const uint32_t budget,
                                                             uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
                                                             uint32_t* __restrict__ n_out, uint32_t* __restrict__ ghist_near,
-                                                            unsigned long long* __restrict__ st, uint32_t* __restrict__ ticket) {
+                                                            unsigned long long* __restrict__ st, uint32_t* __restrict__ ticket,
+                                                            unsigned long long* __restrict__ publish,
+                                                            const uint32_t frame_ticket) {
   __shared__ uint32_t wtot[PRE_BLOCK / 64];
   __shared__ uint32_t s_tile, s_prefix, s_top_end;
   __shared__ uint32_t dh[4][256];
@@ -681,7 +683,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_compact_near(const int P, const u
     if (lane == 0) s_prefix = prefix;
   }
   __syncthreads();
-  if (tile == gridDim.x - 1u && tid == 0) *n_out = s_prefix + agg;  // the candidates of the whole frame
+  if (tile == gridDim.x - 1u && tid == 0) {
+    *n_out = s_prefix + agg;  // the candidates of the whole frame
+    // (the host's copy: a thread whose near candidates turn out to be most of the scene sorts everything up front again)
+    if (publish)
+      __hip_atomic_store(publish, ((unsigned long long)frame_ticket << 32) | (s_prefix + agg), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (agg == 0u) return;  // (workgroup-uniform: nothing to write or count)
   uint32_t pos = s_prefix;
   for (int k = 0; k < w; k++) pos += wtot[k];
@@ -1672,11 +1680,11 @@ hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint
 
 hipError_t launch_compact_near(const FrameParams& fp, GeomState g, const uint32_t* top_hist, uint32_t near_budget,
                                uint32_t* keys_out, uint32_t* vals_out, uint32_t* n_out, uint32_t* ghist_near,
-                               hipStream_t s) {
+                               unsigned long long* publish, uint32_t ticket, hipStream_t s) {
   ProfScope ps(K_DSORT_HIST, s);  // (booked with the depth sort: it takes the place of the digit histogram pass)
   hipLaunchKernelGGL(k_compact_near, dim3((fp.P + COMPACT_TILE - 1) / COMPACT_TILE), dim3(PRE_BLOCK), 0, s, fp.P, g.dkeysA,
                      top_hist, near_budget, keys_out, vals_out, n_out, ghist_near, g.dsort.scanC_status(),
-                     g.dsort.tickets() + 6);
+                     g.dsort.tickets() + 6, publish, ticket);
   return hipGetLastError();
 }
 

@@ -510,6 +510,24 @@ def test_screen_filling_splats_and_long_lists(mode, gpu_device):
 
 
 @pytest.mark.parametrize("mode", MODES)
+def test_depth_ties_keep_id_order(mode, gpu_device):
+    """Thousands of Gaussians share each of a few depths: inside a tile the reference's 64-bit keys then tie and its
+    stable sort leaves such instances in ascending Gaussian id.  Here that order has to survive
+    the depth sort's four look-back passes and the tile sort's LDS-atomic ranking (the production path: ranks from the
+    order in which one ds_add_rtn serves the lanes that hit one address) -- lists bit-exact against the oracle, and the
+    debug forward's own check of every list (k_verify_sorted_lists) stays silent."""
+    sc = S.make_scene(30_000, 400, 300, 31, sh_degree=0)
+    z = sc["means3D"][:, 2]
+    vis = z > 0.5
+    z[vis] = np.float32(1.5) + np.floor(z[vis] / 5.0).astype(np.float32) * np.float32(4.25)   # eight depth levels
+    fr = oracle_forward(sc, mode)
+    keys = np.unique(fr.depths[fr.radii > 0].view(np.uint32))
+    assert keys.size <= 9 and (fr.radii > 0).sum() > 10_000
+    t, fwd = hip_forward(sc, gpu_device, ref_rects=(mode == "reference"))
+    check_forward(sc, fr, fwd, gpu_device)
+
+
+@pytest.mark.parametrize("mode", MODES)
 def test_large_image_many_tile_bits(mode, gpu_device):
     """3000x1700: 188 x 107 = 20116 tiles -> 15 tile-id bits (two 8-bit sort passes), rect origins beyond 127,
     partial tiles on both borders."""
