@@ -339,11 +339,19 @@ static bool order_known(const char* blob) {
 // on "needed", and the caller's stream waits for the frame's go word -- which the near blend itself stores when no
 // quad was left unfinished.  The host never waits for the decision.  GSR_ASYNC_FAR=0 switches the mechanism off (the
 // host then reads the count of unfinished quads from the mailbox and enqueues the far chain if there are any).
+// ONE host thread per process gets the mechanism (the first that asks): a parked far chain waits for a kernel of its own
+// frame on another stream, and with several such pairs multiplexed onto the device's few hardware queues by racing
+// threads, two chains could end up parked in front of each other's frames.  A single pair is always submitted in an
+// order the queues can execute.  Other threads take the host-decided variant.
+static std::atomic<const void*> g_async_owner{nullptr};
+
 static bool async_far_ready(ThreadCtx& c) {
   if (c.async_state) return c.async_state > 0;
   c.async_state = -1;
   const char* e = getenv("GSR_ASYNC_FAR");
   if (e && e[0] == '0') return false;
+  const void* none = nullptr;
+  if (!g_async_owner.compare_exchange_strong(none, &c) && none != &c) return false;
   int can = 0;
   if (hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, c.device) != hipSuccess || !can) {
     (void)hipGetLastError();
