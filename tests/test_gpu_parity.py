@@ -633,24 +633,54 @@ def test_randomised_scenes(gpu_device):
     _random_scenes(np.random.default_rng(20240611), 12, gpu_device)
 
 
+def _random_scene(rng, case, pmax=30_000):
+    W, H = int(rng.integers(17, 700)), int(rng.integers(9, 420))
+    P = int(rng.integers(50, pmax))
+    D = int(rng.integers(0, 4))
+    seed = 1000 + case
+    g = S.make_gaussians(P, seed, sh_degree=D, fovx_deg=float(rng.uniform(35, 100)), aspect=W / H,
+                         zmin=float(rng.uniform(0.3, 2.0)), zmax=float(rng.uniform(3.0, 60.0)))
+    cam = S.make_camera(W, H, fovx_deg=float(rng.uniform(35, 100)), yaw_deg=float(rng.uniform(-25, 25)),
+                        position=tuple(rng.uniform(-0.5, 0.5, 3)))
+    sc = dict(g, **cam, bg=rng.uniform(0, 1, 3).astype(np.float32), colors_precomp=None, cov3D_precomp=None,
+              scale_modifier=float(rng.uniform(0.5, 1.5)))
+    sc["scales"] = (sc["scales"] * rng.uniform(0.5, 2.0, (P, 3))).astype(np.float32)      # stronger anisotropy
+    sc["rotations"] = (sc["rotations"] * rng.uniform(0.5, 2.0, (P, 1))).astype(np.float32)  # used as given (A.3)
+    sc["opacities"] = rng.uniform(0.0, 1.0, (P, 1)).astype(np.float32) ** float(rng.uniform(0.5, 3.0))
+    return sc, seed
+
+
 def _random_scenes(rng, ncases, gpu_device):
     """(also driven with other generator seeds by tools/soak_random_scenes.py)"""
     for case in range(ncases):
-        W, H = int(rng.integers(17, 700)), int(rng.integers(9, 420))
-        P = int(rng.integers(50, 30_000))
-        D = int(rng.integers(0, 4))
-        seed = 1000 + case
-        g = S.make_gaussians(P, seed, sh_degree=D, fovx_deg=float(rng.uniform(35, 100)), aspect=W / H,
-                             zmin=float(rng.uniform(0.3, 2.0)), zmax=float(rng.uniform(3.0, 60.0)))
-        cam = S.make_camera(W, H, fovx_deg=float(rng.uniform(35, 100)), yaw_deg=float(rng.uniform(-25, 25)),
-                            position=tuple(rng.uniform(-0.5, 0.5, 3)))
-        sc = dict(g, **cam, bg=rng.uniform(0, 1, 3).astype(np.float32), colors_precomp=None, cov3D_precomp=None,
-                  scale_modifier=float(rng.uniform(0.5, 1.5)))
-        sc["scales"] = (sc["scales"] * rng.uniform(0.5, 2.0, (P, 3))).astype(np.float32)      # stronger anisotropy
-        sc["rotations"] = (sc["rotations"] * rng.uniform(0.5, 2.0, (P, 1))).astype(np.float32)  # used as given (A.3)
-        sc["opacities"] = rng.uniform(0.0, 1.0, (P, 1)).astype(np.float32) ** float(rng.uniform(0.5, 3.0))
+        sc, seed = _random_scene(rng, case)
         for mode in MODES:
             _full_check(sc, gpu_device, seed=seed, stress=True, mode=mode)
+
+
+def _random_near_far(rng, ncases, gpu_device):
+    """Random scenes (as above, plus a stack of large opaque splats in front of every other one so that some tiles
+    saturate early) binned near/far with a random budget, with and without far-chain speculation: bit-identical to
+    the one-chain frame of the same library (_check_near_far_against_one_chain).  Also driven by
+    tools/soak_random_scenes.py, under the knobs of test_far_speculation_variants."""
+    try:
+        for case in range(ncases):
+            sc, seed = _random_scene(rng, case, pmax=60_000)
+            if case % 2:
+                k = min(int(rng.integers(8, 80)), sc["means3D"].shape[0])
+                sc["means3D"][:k, :2] *= 0.2
+                sc["means3D"][:k, 2] = rng.uniform(0.6, 1.2, k).astype(np.float32)
+                sc["scales"][:k] = np.float32(0.29 / max(sc["scale_modifier"], 1.0))
+                sc["opacities"][:k] = 0.97
+            for spec in (None, True):
+                _check_near_far_against_one_chain(sc, gpu_device, int(rng.integers(1, 120)), speculate_far=spec)
+    finally:
+        G.set_near_far_hints(None, None)
+        G.set_far_speculation(None)
+
+
+def test_near_far_randomised(gpu_device):
+    _random_near_far(np.random.default_rng(20241004), 8, gpu_device)
 
 
 @pytest.mark.parametrize("mode", MODES)
