@@ -1621,7 +1621,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_mark_visible(int P, const float* 
 bool preprocess_counts_depth_digits(const FrameParams& fp, const float* shs, const float* colors_precomp) {
   // (GSR_PRE_HIST_MIN_P: tests run the paths that hang on these histograms -- the near limit, the partial depth sort --
   // on small scenes)
-  static const long min_p = getenv("GSR_PRE_HIST_MIN_P") ? atol(getenv("GSR_PRE_HIST_MIN_P")) : (1 << 20);
+  // From 128 k Gaussians (with one workgroup per CU up to 1 M, so that a workgroup walks several blocks between its ~770
+  // flush atomics: 640x512 / 300 k: k_preprocess +2.5 us, k_sort_hist_all's 8.6 us launch gone; 500 k: +4.8 / -9.6).
+  static const long min_p = getenv("GSR_PRE_HIST_MIN_P") ? atol(getenv("GSR_PRE_HIST_MIN_P")) : (1 << 17);
   if (fp.P <= min_p) return false;
   return !((shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0);
 }
@@ -1642,7 +1644,10 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
   // path, not by latency or VALU), and every workgroup ends with ~770 histogram flush atomics and one same-address count
   // atomic, so fewer and longer-lived workgroups win
   static const int wg_per_cu = getenv("GSR_PRE_WG_PER_CU") ? atoi(getenv("GSR_PRE_WG_PER_CU")) : 3;  // experiment knob
-  const int max_wg = (stage ? 3 : wg_per_cu) * 256, rounds = (nb + max_wg - 1) / max_wg;
+  // (up to 1 M Gaussians a single workgroup per CU when the digits are counted here: see preprocess_counts_depth_digits)
+  static const bool wg_forced = getenv("GSR_PRE_WG_PER_CU") != nullptr;
+  const bool few_wg = ghist_acc != nullptr && fp.P <= (1 << 20) && !wg_forced;
+  const int max_wg = (stage ? 3 : few_wg ? 1 : wg_per_cu) * 256, rounds = (nb + max_wg - 1) / max_wg;
   const dim3 grid(rounds ? (nb + rounds - 1) / rounds : 1);
   if (stage)
     hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(PRE_BLOCK), stage, s, fp, means3D, scales, rotations, opacities,

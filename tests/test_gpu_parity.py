@@ -384,7 +384,7 @@ def test_far_speculation_variants(env, gpu_device):
     chosen by a knob that is read once per process (child process):
     GSR_ASYNC_FAR=0 -- without stream-side waits the near blend's count of unfinished quads goes to the host mailbox and
     the host enqueues the far chain only if it is non-zero;
-    GSR_PRE_HIST_MIN_P=0 -- k_preprocess counts the depth keys' digits on these small scenes too (as it does from 1 M
+    GSR_PRE_HIST_MIN_P=0 -- k_preprocess counts the depth keys' digits on these small scenes too (as it does from 128 k
     Gaussians), so the frames that expect an idle far chain take the PARTIAL depth sort: near candidates compacted and
     sorted on their own, the full sort left to the far chain -- which runs it in the miss cases here."""
     import subprocess
