@@ -368,6 +368,42 @@ static bool async_far_ready(ThreadCtx& c) {
     return false;
   }
   (void)hipDeviceSynchronize();
+  // The API is marked Beta: before a caller's stream is ever made to wait on it, the whole hand-off is rehearsed once on
+  // two streams of the library's own -- kernel stores `decide`, the far stream's wait passes, its kernel stores `go`,
+  // the other stream's wait passes -- and must have completed within three seconds (the first launch loads code objects).  If not, the mechanism stays off for this
+  // thread (the rehearsal's streams are abandoned, not destroyed: one of them may still be parked).
+  {
+    hipStream_t probe = nullptr;
+    (void)hipGetLastError();  // (a stale error of some earlier call must not be taken for one of these launches')
+    int step = 0;
+    bool ok = hipStreamCreateWithFlags(&probe, hipStreamNonBlocking) == hipSuccess;
+    uint32_t* decide = static_cast<uint32_t*>(a);
+    uint32_t* go = static_cast<uint32_t*>(b);
+    if (ok) { step = 1; ok = hipStreamWaitValue32(st, decide, 2u, hipStreamWaitValueGte) == hipSuccess; }
+    if (ok) { step = 2; ok = launch_release_go(Count{nullptr, 0}, go, 1u, st) == hipSuccess; }
+    if (ok) { step = 3; ok = launch_release_go(Count{nullptr, 0}, decide, 2u, probe) == hipSuccess; }
+    if (ok) { step = 4; ok = hipStreamWaitValue32(probe, go, 1u, hipStreamWaitValueGte) == hipSuccess; }
+    if (ok) {
+      step = 5;
+      const std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+      hipError_t q = hipErrorNotReady, q2 = hipErrorNotReady;
+      while (std::chrono::steady_clock::now() - t0 < std::chrono::milliseconds(3000)) {
+        if (q == hipErrorNotReady) q = hipStreamQuery(probe);
+        if (q2 == hipErrorNotReady) q2 = hipStreamQuery(st);
+        if (q != hipErrorNotReady && q2 != hipErrorNotReady) break;
+      }
+      ok = q == hipSuccess && q2 == hipSuccess;
+    }
+    if (!ok) {
+      (void)hipGetLastError();
+      fprintf(stderr, "[gsr] stream-side waits did not complete their rehearsal (step %d): far-chain speculation stays on "
+                      "the host\n", step);
+      return false;
+    }
+    (void)hipStreamDestroy(probe);
+    if (hipMemset(a, 0, 8) != hipSuccess || hipMemset(b, 0, 8) != hipSuccess) return false;
+    (void)hipDeviceSynchronize();
+  }
   c.sig_decide = static_cast<uint32_t*>(a);
   c.sig_go = static_cast<uint32_t*>(b);
   c.far_stream = st;
