@@ -55,9 +55,9 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
     R = instances, R_bwd = sum over tiles of tile_last (list entries the backward has to walk)."""
     kb = 2 if tiles <= 65536 else 4
     return {
-        # in: 56 B @M=1; out: radii 4, gpack (tile count + rect) 8, touched 1, clamped 1, depth-sort pair 8 per Gaussian
-        # and the 48-B splat record per visible one (cov3D and a separate depth array are no longer written)
-        "k_preprocess": P * (44 + 12 * M) + P * 22 + P_vis * 48,
+        # in: 56 B @M=1; out: radii 4, gpack (tile count + rect) 8, touched 1, clamped 1, depth-sort key 4 per Gaussian
+        # and the 48-B splat record per visible one (cov3D, a separate depth array and the id array are no longer written)
+        "k_preprocess": P * (44 + 12 * M) + P * 18 + P_vis * 48,
         "k_point_offsets": P * 8,                                 # debug forwards only
         "k_sort_hist[depth]": P * 4, "k_sort_scatter[depth]": P * 16,
         # order + gpack gather in; 16-byte depth-ordered descriptor out; slotinfo for the Gaussians with instances

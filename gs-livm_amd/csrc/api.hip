@@ -485,7 +485,8 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
       all.dev = nullptr;
       all.cap = fp.P;
       STAGE(launch_clear_words(all, g.dsort.words + 1024, g.dsort.scan_off - 1024, stream));
-      STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, all, dord.ghist, stream));
+      STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, all, dord.ghist,
+                              /*vals_are_positions=*/true, stream));
     }
     STAGE(launch_live_sat(fp, im, g.total + 9, cnt, stream));  // which tiles did the near chain leave unfinished
     STAGE(launch_scan_offsets_far(fp, g, cnt, ch.base, im.live_sat, chunk_first, b.tsort.counts, c.mailbox_dev + 1,
@@ -670,10 +671,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     c.near_count_pending = true;
     c.near_count_ticket = c.ticket;
     STAGE(launch_depth_sort(g.dkeysB, g.dvalsB, g.nkeys2, g.nvals2, g.dsort, Count{g.total + 15, P},
-                            g.dsort.ghist_near((size_t)P), stream));
+                            g.dsort.ghist_near((size_t)P), /*vals_are_positions=*/false, stream));
     near_order = g.dvalsB;
   } else {
-    STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, Count{nullptr, P}, ghist_acc, stream));
+    STAGE(launch_depth_sort(g.dkeysA, g.order, g.dkeysB, g.dvalsB, g.dsort, Count{nullptr, P}, ghist_acc,
+                            /*vals_are_positions=*/true, stream));
   }
   // what a chain needs to know about the depth order (enqueue_chain)
   const DepthOrder dord = {near_order, partial_sort, ghist_acc};

@@ -124,7 +124,8 @@ struct GeomState {
   uint2* slotinfo;          // {first slot of the Gaussian's instance run, x0 | y0 << 10 | rect_width << 20}
   uint2* gpack;             // {tiles_touched, packed rect} per Gaussian: ONE 8-byte gather in depth order (the only
                             // copy of the tile counts)
-  uint32_t* order;          // [P] Gaussian ids sorted by (depth bits, id); culled Gaussians last.  = dvalsA
+  uint32_t* order;          // [P] Gaussian ids sorted by (depth bits, id); culled Gaussians last.  = dvalsA (written by
+                            // the depth sort only: the unsorted ids are the positions 0 .. P-1)
   uint32_t* dkeysA;         // [P] depth-sort ping-pong buffers
   uint32_t* dkeysB;
   uint32_t* dvalsB;
@@ -334,8 +335,10 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
 // (n.dev != nullptr: the pair count is read on the device -- the near sort of a partial depth sort, whose tile size is
 // that of a sort of n.cap pairs so that both use the scratch alike; n.gate: the gated full sort of an asynchronous
 // frame's far chain)
+// vals_are_positions: the values of the unsorted pairs are 0 .. n-1 and are not read (the Gaussians' ids: k_preprocess
+// writes no id array)
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
-                             Count n, const uint32_t* ghist, hipStream_t s);
+                             Count n, const uint32_t* ghist, bool vals_are_positions, hipStream_t s);
 hipError_t launch_ranges_from_counts(uint2* ranges, int T, uint32_t list_base, Count gate, hipStream_t s);
 hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t* point_list, const float4* splats,
                                       uint32_t* violations, hipStream_t s);

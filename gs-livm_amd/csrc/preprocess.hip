@@ -422,9 +422,9 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   g.gpack[idx] = make_uint2(tiles, tiles ? rect_packed : 0u);
   g.touched[idx] = 0;  // backward bookkeeping starts clean (the backward clears what it sets)
   g.clamped[idx] = clamp_out;
-  // (key, value) pairs of the per-Gaussian depth sort; Gaussians without instances sort to the end
+  // key of the per-Gaussian depth sort (its value is the position, idx: no id array is written); Gaussians without
+  // instances sort to the end
   g.dkeysA[idx] = dkey;
-  g.order[idx] = (uint32_t)idx;
   if (dup) { tiles = 0u; dkey = 0xFFFFFFFFu; }  // a duplicate lane is not counted below
   {
     // The 48-byte records of a wave's 64 Gaussians leave as three fully contiguous 1-KB stores: each lane parks its record

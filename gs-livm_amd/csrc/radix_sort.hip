@@ -347,13 +347,13 @@ hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
 // there.  sc.words (ghist | tickets | status) must be zero on entry: k_preprocess clears it.
 template <int TILE, int NW>
 static void depth_sort_passes(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
-                              Count n, bool arank, const uint32_t* ghist, hipStream_t s) {
+                              Count n, bool arank, const uint32_t* ghist, bool vals_are_positions, hipStream_t s) {
   const int ntiles = (n.cap + TILE - 1) / TILE;
   bool inA = true;
   for (int p = 0; p < 4; p++) {
     ProfScope ps(K_DSORT_SCATTER, s);
     const uint32_t* kin = inA ? keysA : keysB;
-    const uint32_t* vin = inA ? valsA : valsB;
+    const uint32_t* vin = (p == 0 && vals_are_positions) ? nullptr : inA ? valsA : valsB;
     uint32_t* kout = inA ? keysB : keysA;
     uint32_t* vout = inA ? valsB : valsA;
     if (arank)
@@ -369,7 +369,7 @@ static void depth_sort_passes(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB,
 }
 
 hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, DepthSortScratch sc,
-                             Count n, const uint32_t* ghist, hipStream_t s) {
+                             Count n, const uint32_t* ghist, bool vals_are_positions, hipStream_t s) {
   if (n.cap <= 0) return hipSuccess;
   if (!ghist) {  // the producer of the keys did not count the digits: one histogram pass over them (host-known counts only)
     ghist = sc.ghist();
@@ -382,11 +382,11 @@ hipError_t launch_depth_sort(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, 
   // full sort: with 4096-pair tiles instead of 8192 at 2 M its passes measured 16.5 instead of 14.5 us)
   const size_t tile = depth_sort_tile((size_t)n.cap);
   if (tile == (size_t)SORT_TILE_SMALL)
-    depth_sort_passes<SORT_TILE_SMALL, 4>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, s);
+    depth_sort_passes<SORT_TILE_SMALL, 4>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, vals_are_positions, s);
   else if (tile == (size_t)SORT_TILE)
-    depth_sort_passes<SORT_TILE, 4>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, s);
+    depth_sort_passes<SORT_TILE, 4>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, vals_are_positions, s);
   else
-    depth_sort_passes<SORT_TILE_BIG, 8>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, s);
+    depth_sort_passes<SORT_TILE_BIG, 8>(keysA, valsA, keysB, valsB, sc, n, arank, ghist, vals_are_positions, s);
   return hipGetLastError();
 }
 

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(64 * NW) void k_sort_scatter(const K* __restrict__ 
       const size_t i = base + (size_t)s * 64 + lane;
       const bool valid = i < (size_t)n;
       key[s] = valid ? (uint32_t)keys_in[i] : 0u;
-      val[s] = valid ? vals_in[i] : 0u;
+      val[s] = !valid ? 0u : vals_in ? vals_in[i] : (uint32_t)i;  // (no value array: the values are the positions)
     }
     scatter_core<K, LB, ARANK, NW, TILE, COUNT>(L, key, val, tile, keys_out, vals_out, n, shift, nbits, counts, chunk_base,
                                                 digit_total, status, key_count);
