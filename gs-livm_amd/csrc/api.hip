@@ -1,6 +1,20 @@
 // api.hip -- the C ABI of libgsraster_hip.so (include/gsraster.h): argument checks, blob carving and
 // stage sequencing.  Restates the ORCHESTRATION of CudaRasterizer::Rasterizer::forward / backward
 // (reference rasterizer_impl.cu:181-342, :346-457); all device work is in the sibling .hip files.
+//
+// How a forward is sequenced (gsr_forward):
+//   synchronous  (a thread's first, debug, GSR_SYNC_FORWARD)  k_preprocess + depth sort, host waits for num_rendered
+//                (mailbox), exact binning blob, one binning chain (enqueue_chain) + blend;
+//   speculative  blob sized from the thread's recent frames, everything enqueued at once, counts read on the device,
+//                the mailbox read after the last enqueue; overflow -> the chain is enqueued again with the exact size;
+//   near / far   (dense frames) two chains over the Gaussians in depth order -- near up to a budget, then only the far
+//                Gaussians whose rectangle still holds an unfinished tile;
+//   + far-chain speculation (after two split frames that left nothing unfinished): the far chain is not enqueued on
+//                the caller's stream -- ASYNCHRONOUS: gated, on the library's own stream behind a stream-side wait for
+//                the near blend's decision, the caller's stream waiting for the frame's go word; or HOST-DECIDED: the
+//                count of unfinished quads comes back through the mailbox -- and only the near candidates are sorted
+//                by depth up front (partial depth sort), the full sort moving into the far chain.
+// Per host thread and device: ThreadCtx (mailbox, counters, histogram pair, predictions, the second stream).
 #include "../../include/gsraster.h"
 
 #include <algorithm>

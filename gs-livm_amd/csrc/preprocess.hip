@@ -1,9 +1,12 @@
 // preprocess.hip -- per-Gaussian and per-instance bookkeeping stages of the MI355X rasterizer (gfx950):
 //   F1  k_preprocess        project / cull / EWA / SH->RGB, footprint-box tile rectangle, 48-B splat record,
-//                           depth-sort pair + the depth sort's digit histograms; publishes num_rendered to the
-//                           host mailbox (last workgroup)
+//                           depth-sort key + the depth sort's digit histograms and the tile counts per top key
+//                           byte; publishes num_rendered to the host mailbox (last workgroup)
+//   F2' k_compact_near      partial depth sort: the near candidates of a near/far frame, compacted in id order
 //   F3  k_scan_offsets      single-launch (look-back) scan of the tile counts in depth order; 16-byte emission
-//                           descriptors in depth order, slotinfo, emission chunk table
+//                           descriptors in depth order, slotinfo, emission chunk table; near phase of a near/far
+//                           frame: up to the Gaussian in whose slot run the budget falls
+//       k_scan_offsets_far  the far Gaussians whose rectangle still holds an unfinished tile
 //   F4  k_emit              output-centric emission of (tile id, Gaussian id) pairs in depth order; with 16-bit
 //                           tile ids it only counts the digits of the sort's first pass, and
 //       k_emit_scatter      generates the pairs inside that pass (they never reach HBM unsorted)

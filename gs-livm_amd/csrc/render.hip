@@ -3,23 +3,24 @@
 // Replaces renderCUDA forward (reference forward.cu:291-407) and renderCUDA backward
 // (reference backward.cu:438-603).
 //
-// Shape of both kernels (NOT the reference's 16x16-thread / 32-lane-warp structure):
-//   * one 256-thread workgroup per 16x16 tile = 4 waves; wave w owns the 8x8 pixel QUAD
-//     (w&1, w>>1) of the tile, lane l the pixel (l&7, l>>3) inside it;
-//   * the tile's depth-sorted splat list is staged through LDS in chunks of 256: every thread
-//     gathers ONE 48-B splat record (3 x dwordx4) and tests its exact-conservative footprint box
-//     (hx, hy from the preprocess) against the four quads; four 64-bit wave ballots per loader wave
-//     form per-quad hit masks in LDS -- the in-tile compaction;
-//   * each wave then walks only the set bits of its own quad's masks (scalar bit scan, s_ff1), reading
-//     the record by LDS broadcast, so a splat that cannot touch a quad costs that wave nothing.
-//     Skipping is exact: a skipped (quad, splat) pair has alpha < 1/255 for every pixel, which the
-//     reference discards as well.
-// Forward stops per wave as soon as its 64 pixels are saturated and per tile when all four are.
-// Backward emits, for each (tile, splat) instance, ONE 9-float gradient record into the splat's
-// slot (plain 16-B stores, no atomics): DPP wave reduction over the 64 pixels of a quad, partials
-// of the (up to) four quads combined in fixed order.  k_gaussian_backward sums a Gaussian's
-// records.  The reference issues 9 global atomicAdds per (pixel, splat) instead (backward.cu:565,
-// 591-600) and is run-to-run non-deterministic; this path is bitwise reproducible.
+// Shapes (NOT the reference's 16x16-thread / 32-lane-warp structure; details at each kernel):
+//   * forward, k_blend_forward: ONE WAVE PER 8x8 PIXEL QUAD, no workgroup barrier in the blending; a wave streams its
+//     tile's depth-sorted list 64 entries at a time -- one 48-B splat record per lane, exact ellipse-vs-quad test, one
+//     ballot, records published to a wave-private LDS image -- and walks only the set bits (scalar bit scan, LDS
+//     broadcast), so a splat that cannot touch the quad costs it nothing.  Skipping is exact: a skipped pair has
+//     alpha < 1/255 for every pixel, which the reference discards as well.  A wave stops when its 64 pixels have.
+//     Near/far frames (api.hip) run it as phase 1 (near segment; unfinished quads park their state; the launch's last
+//     workgroup counts them and, in an asynchronous frame, opens the far chain or releases the caller's stream) and
+//     phase 2 (far segment, gated);
+//   * backward, k_blend_backward_tile (frames of >= 3072 tiles): ONE WAVE PER 16x16 TILE, four pixels per lane, no
+//     barriers: the nine partial sums of a (tile, splat) pair are accumulated over the lane's pixels first and reduced
+//     across the wave once (v_permlane32_swap / v_permlane16_swap + DPP); four lanes store the raw sums as ONE record
+//     into the splat's slot (plain stores, no atomics).  k_blend_backward (smaller frames): workgroup per tile, wave
+//     per quad, per-quad partials combined in fixed order.  Both take the tiles longest walk first (k_tile_order).
+//   k_gather_records (preprocess.hip) sums a Gaussian's records.  The reference issues 9 global atomicAdds per
+//   (pixel, splat) instead (backward.cu:565, 591-600) and is run-to-run non-deterministic; this path is bitwise
+//   reproducible.
+// Also here: k_live_sat (which tiles the near chain left unfinished), k_release_go (end of an asynchronous far chain).
 #include <cstdlib>
 
 #include "gsr_internal.hpp"
