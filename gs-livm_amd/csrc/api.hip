@@ -326,27 +326,34 @@ static int wait_num_rendered(ThreadCtx& c, hipStream_t stream, uint32_t* R_out, 
   }
 }
 
-// Image blobs whose backward tile order (k_tile_order) was computed by the forward that filled them: gsr_backward -- on
-// whatever host thread autograd runs it -- skips its own launch for those.  An entry exists iff the MOST RECENT forward
-// on that blob pointer computed the order: every forward drops its blob's entry on entry.
-static std::mutex g_order_mu;
-static const char* g_order_blobs[16] = {nullptr};
-static unsigned g_order_pos = 0;
+// What gsr_backward -- on whatever host thread autograd runs it -- may know about the forward that filled an image blob:
+// ORDER: the backward's tile order (k_tile_order) was computed by that forward; SPLIT: it was a near/far frame (the
+// gradient gather then walks the emitted Gaussians' descriptors instead of compacting P flags).  A note exists iff the
+// MOST RECENT forward on that blob pointer left it: every forward drops its blob's note on entry.
+enum : unsigned { NOTE_ORDER = 1u, NOTE_SPLIT = 2u };
+static std::mutex g_note_mu;
+static struct { const char* blob; unsigned flags; } g_notes[16] = {};
+static unsigned g_note_pos = 0;
 static void order_forget(const char* blob) {
-  std::lock_guard<std::mutex> lk(g_order_mu);
-  for (auto& e : g_order_blobs)
-    if (e == blob) e = nullptr;
+  std::lock_guard<std::mutex> lk(g_note_mu);
+  for (auto& e : g_notes)
+    if (e.blob == blob) { e.blob = nullptr; e.flags = 0u; }
 }
-static void order_remember(const char* blob) {
-  std::lock_guard<std::mutex> lk(g_order_mu);
-  g_order_blobs[g_order_pos++ & 15u] = blob;
+static void frame_note(const char* blob, unsigned flags) {
+  std::lock_guard<std::mutex> lk(g_note_mu);
+  for (auto& e : g_notes)
+    if (e.blob == blob) { e.flags |= flags; return; }
+  g_notes[g_note_pos & 15u].blob = blob;
+  g_notes[g_note_pos++ & 15u].flags = flags;
 }
-static bool order_known(const char* blob) {
-  std::lock_guard<std::mutex> lk(g_order_mu);
-  for (auto& e : g_order_blobs)
-    if (e == blob) return true;
-  return false;
+static void order_remember(const char* blob) { frame_note(blob, NOTE_ORDER); }
+static unsigned frame_notes(const char* blob) {
+  std::lock_guard<std::mutex> lk(g_note_mu);
+  for (auto& e : g_notes)
+    if (e.blob == blob) return e.flags;
+  return 0u;
 }
+
 // ---- asynchronous near/far frames ------------------------------------------------------------------------------
 // Stream-side hand-off instead of a host round trip (hipStreamWaitValue32, where the device offers it): the far chain
 // is enqueued on the library's own stream behind a wait for the near blend's decision word, every kernel of it gated
@@ -838,6 +845,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       }
       c.last_was_near_far = true;
       redo = R_far > capB;
+      if (!redo) frame_note(iblob, NOTE_SPLIT);
     } else {
       key = (int)hint;
       char* bblob = binning_alloc(binning_ctx, gsr_binning_bytes(key));
@@ -972,8 +980,10 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
   if (R > 0) {
     // inst_flag, touched and total[2] are zero here: the forward initialises them and the gather kernels
     // below clear what the blend backward sets, so the same blobs can be differentiated again.
-    STAGE(launch_blend_backward(fp, g, b, im, background, dL_dpix, dL_dacc, order_known(image_buffer), stream));
-    STAGE(launch_gather_records(fp, g, b, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, stream));
+    const unsigned notes = frame_notes(image_buffer);
+    STAGE(launch_blend_backward(fp, g, b, im, background, dL_dpix, dL_dacc, (notes & NOTE_ORDER) != 0u, stream));
+    STAGE(launch_gather_records(fp, g, b, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, (notes & NOTE_SPLIT) != 0u,
+                                stream));
   }
   STAGE(launch_gaussian_backward(fp, g, b, radii, means3D, scales, rotations, colors_precomp ? nullptr : shs,
                                  cov3D_precomp, viewmatrix, projmatrix, campos, colors_precomp != nullptr, dL_dmean2D,

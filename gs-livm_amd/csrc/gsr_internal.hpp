@@ -324,8 +324,10 @@ struct EmitFusion {
 hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_t* vals_out, int nbits0,
                                const uint32_t* counts, const uint32_t* chunk_base, const uint32_t* digit_total,
                                bool arank, hipStream_t s);
+// (split_frame: a near/far frame -- the Gaussians with records are looked for among the emitted ones' descriptors)
 hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningState b, float* dL_dmean2D,
-                                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, hipStream_t s);
+                                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, bool split_frame,
+                                 hipStream_t s);
 // Stable LSD radix sort of n (u32, u32) pairs on key bits [0, end_bit); buffers ping-pong between
 // (keysA, valsA) and (keysB, valsB), starting in A when start_in_A.
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,

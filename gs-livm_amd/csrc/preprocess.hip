@@ -1272,13 +1272,18 @@ __device__ __forceinline__ void swap_add16_(float& a, float& b) {
 __global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
     GeomState g, const float4* __restrict__ grad_inst, uint8_t* __restrict__ inst_flag,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
-    float* __restrict__ dL_dcolor, const float ddelx_dx, const float ddely_dy) {
+    float* __restrict__ dL_dcolor, const float ddelx_dx, const float ddely_dy, const int P, const bool from_descriptors) {
   const int lane = threadIdx.x & 63;
   const uint32_t nwaves = gridDim.x * (PRE_BLOCK / 64);
   const uint32_t wid = blockIdx.x * (PRE_BLOCK / 64) + (threadIdx.x >> 6);
-  const uint32_t count = g.total[2];
+  // Which Gaussians have records: the list k_compact_touched made of the flagged ones -- or, in a near/far frame, simply
+  // the Gaussians the frame emitted (a few per cent of the scene: the near chain's descriptors [0, total[7]) and the far
+  // chain's [0, total[10])), each asked for its flag: no compaction launch over all P flags
+  const uint32_t nA = from_descriptors ? g.total[7] : 0u;
+  const uint32_t count = from_descriptors ? nA + g.total[10] : g.total[2];
   for (uint32_t q = wid; q < count; q += nwaves) {
-    const uint32_t id = g.tlist[q];
+    const uint32_t id = !from_descriptors ? g.tlist[q] : q < nA ? g.sdesc[q].y : g.sdescB[q - nA].y;
+    if (from_descriptors && (id >= (uint32_t)P || !g.touched[id])) continue;  // (emitted, but no pixel took it)
     const size_t first = g.slotinfo[id].x;
     const uint32_t n = g.gpack[id].x;
     float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0;
@@ -1739,9 +1744,10 @@ hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_
 }
 
 hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningState b, float* dL_dmean2D,
-                                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, hipStream_t s) {
+                                 float* dL_dconic, float* dL_dopacity, float* dL_dcolor, bool split_frame,
+                                 hipStream_t s) {
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
-  {
+  if (!split_frame) {
     ProfScope ps(K_COMPACT_TOUCHED, s);
     hipLaunchKernelGGL(k_compact_touched, dim3((nb + 15) / 16), dim3(PRE_BLOCK), 0, s, fp.P, g.touched, g.tlist,
                        g.total + 2);
@@ -1753,7 +1759,7 @@ hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningStat
     const int want = (fp.P + PRE_BLOCK / 64 - 1) / (PRE_BLOCK / 64);
     const int grid = want < 4096 ? want : 4096;
     hipLaunchKernelGGL(k_gather_records, dim3(grid), dim3(PRE_BLOCK), 0, s, g, b.grad_inst, b.inst_flag, dL_dmean2D,
-                       dL_dconic, dL_dopacity, dL_dcolor, 0.5f * (float)fp.W, 0.5f * (float)fp.H);
+                       dL_dconic, dL_dopacity, dL_dcolor, 0.5f * (float)fp.W, 0.5f * (float)fp.H, fp.P, split_frame);
   }
   return hipGetLastError();
 }
