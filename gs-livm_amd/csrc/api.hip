@@ -238,6 +238,7 @@ struct ThreadCtx {
   bool lazy_pending = false;                  // the last forward returned before its far-chain decision was known
   uint32_t lazy_ticket = 0, lazy_near = 0;
   const uint32_t* top_hist = nullptr;         // this forward's [count | tile sum] by top key byte (k_preprocess), or null
+  ~ThreadCtx();                               // (a thread that ends gives the asynchronous mechanism back)
 };
 static thread_local ThreadCtx g_ctx;
 
@@ -366,6 +367,22 @@ static unsigned frame_notes(const char* blob) {
 // order the queues can execute.  Other threads take the host-decided variant.
 static std::atomic<const void*> g_async_owner{nullptr};
 
+// A host thread that ends: its far stream is drained and destroyed, its signal words freed, and the mechanism is free
+// for another thread.  (Left behind, the stream of an ended thread kept the process from exiting: seen with two
+// rendering threads under pytest.)
+ThreadCtx::~ThreadCtx() {
+  if (far_stream) {
+    (void)hipStreamSynchronize(far_stream);  // (every wait on it is satisfied by a frame that has been enqueued in full)
+    (void)hipStreamDestroy(far_stream);
+    far_stream = nullptr;
+  }
+  if (sig_decide) (void)hipFree(sig_decide);
+  if (sig_go) (void)hipFree(sig_go);
+  sig_decide = sig_go = nullptr;
+  const void* me = this;
+  (void)g_async_owner.compare_exchange_strong(me, nullptr);
+}
+
 static bool async_far_ready(ThreadCtx& c) {
   if (c.async_state) return c.async_state > 0;
   c.async_state = -1;
@@ -400,9 +417,11 @@ static bool async_far_ready(ThreadCtx& c) {
     bool ok = hipStreamCreateWithFlags(&probe, hipStreamNonBlocking) == hipSuccess;
     uint32_t* decide = static_cast<uint32_t*>(a);
     uint32_t* go = static_cast<uint32_t*>(b);
-    if (ok) { step = 1; ok = hipStreamWaitValue32(st, decide, 2u, hipStreamWaitValueGte) == hipSuccess; }
-    if (ok) { step = 2; ok = launch_release_go(Count{nullptr, 0}, go, 1u, st) == hipSuccess; }
-    if (ok) { step = 3; ok = launch_release_go(Count{nullptr, 0}, decide, 2u, probe) == hipSuccess; }
+    // (enqueued in the order of the dependencies, as a frame's operations are: streams share the device's few hardware
+    // queues, and a wait enqueued ahead of the kernel it waits for would block that kernel if both landed in one queue)
+    if (ok) { step = 1; ok = launch_release_go(Count{nullptr, 0}, decide, 2u, probe) == hipSuccess; }
+    if (ok) { step = 2; ok = hipStreamWaitValue32(st, decide, 2u, hipStreamWaitValueGte) == hipSuccess; }
+    if (ok) { step = 3; ok = launch_release_go(Count{nullptr, 0}, go, 1u, st) == hipSuccess; }
     if (ok) { step = 4; ok = hipStreamWaitValue32(probe, go, 1u, hipStreamWaitValueGte) == hipSuccess; }
     if (ok) {
       step = 5;

@@ -402,6 +402,58 @@ def test_far_speculation_variants(env, gpu_device):
     assert out.returncode == 0 and "variant ok" in out.stdout, (out.stdout + out.stderr)[-3000:]
 
 
+def test_two_host_threads_render_concurrently(gpu_device):
+    """The reference calls the rasterizer from several host threads.  Two threads, each on a stream of
+    its own, render and differentiate a dense scene eight times at the same moment, every frame split near/far with
+    far-chain speculation forced: one thread gets the asynchronous mechanism (one per process), the other decides on
+    the host; per-thread state (mailbox, counters, histogram pair, predictions) must not mix.  Every frame of both
+    threads equals, bit for bit, the frame the main thread rendered alone."""
+    import threading
+    dev = gpu_device
+    sc = S.make_scene(30_000, 320, 208, 23, sh_degree=0)
+    sc["means3D"][:64, :2] = 0.0
+    sc["means3D"][:64, 2] = np.linspace(0.5, 0.9, 64, dtype=np.float32)
+    sc["scales"][:64] = 0.29
+    sc["opacities"][:64] = 0.98
+    dcol, dacc = S.make_upstream_grads(sc["W"], sc["H"], 5)
+    G.set_binning_capacity_hint(0)
+    t0, one = hip_forward(sc, dev, debug=False)                     # the reference frame: synchronous, one chain
+    g_ref = hip_backward(sc, t0, one, dcol, dacc, dev, debug=False)
+    torch.cuda.synchronize()
+    errors, skipped = [], []
+
+    def worker(k):
+        try:
+            stream = torch.cuda.Stream(device=dev)
+            with torch.cuda.stream(stream):
+                G.set_binning_capacity_hint(0)
+                hip_forward(sc, dev, debug=False)                   # this thread's first forward is synchronous
+                for it in range(8):
+                    G.set_near_far_hints(200, None)
+                    G.set_far_speculation(True)
+                    t, fwd = hip_forward(sc, dev, debug=False, near_far=True)
+                    g = hip_backward(sc, t, fwd, dcol, dacc, dev, debug=False)
+                    for i, (x, y) in enumerate(zip(one[1:5], fwd[1:5])):
+                        assert torch.equal(x, y), (k, it, i)
+                    for name in g_ref:
+                        assert np.array_equal(g_ref[name], g[name]), (k, it, name)
+                    stream.synchronize()
+                    skipped.append(G.last_far_skipped())
+                G.set_near_far_hints(None, None)
+                G.set_far_speculation(None)
+        except BaseException as e:  # noqa: BLE001 -- reported by the main thread
+            errors.append((k, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=120)
+    assert not any(th.is_alive() for th in threads), "a rendering thread hangs"
+    assert not errors, errors
+    assert len(skipped) == 16 and all(skipped)                      # every frame completed without a far chain
+
+
 def test_c3_near_far(c3, gpu_device):
     """BASELINE C3 binned near/far with the default budget (the configuration bench.py times): bit-identical images,
     n_contrib and gradients; every tile is finished by the near phase and the far chain has nothing left to emit."""
