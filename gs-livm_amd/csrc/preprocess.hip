@@ -457,7 +457,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the image is rewritten by the wave's next block)
     __builtin_amdgcn_wave_barrier();
   }
-  if (!STAGED && ghist_acc) {
+  if constexpr (!STAGED) if (ghist_acc) {
     // Gaussians without instances all carry the key 0xFFFFFFFF: counted per wave, not per lane (one address)
     const bool has = !dup, none = has && dkey == 0xFFFFFFFFu;
     const uint64_t nm = __ballot(none);

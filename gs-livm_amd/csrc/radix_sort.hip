@@ -121,10 +121,11 @@ __global__ __launch_bounds__(256) void k_sort_scan_columns(uint32_t* __restrict_
 #pragma unroll
     for (int k = 0; k < 16; k++) {
       const int t = c0 + 64 * k + lane;
-      if (c0 + 64 * k >= ntiles) break;  // (wave-uniform)
-      const uint32_t inc = wave_incl_scan(v[k], lane);
-      if (t < ntiles) counts[(size_t)t * 256 + d] = carry + inc - v[k];
-      carry += __shfl(inc, 63, 64);
+      if (c0 + 64 * k < ntiles) {  // (wave-uniform)
+        const uint32_t inc = wave_incl_scan(v[k], lane);
+        if (t < ntiles) counts[(size_t)t * 256 + d] = carry + inc - v[k];
+        carry += __shfl(inc, 63, 64);
+      }
     }
   }
   if (lane == 0) digit_total[d] = carry;
