@@ -409,7 +409,7 @@ static bool async_far_ready(ThreadCtx& c) {
   // The API is marked Beta: before a caller's stream is ever made to wait on it, the whole hand-off is rehearsed once on
   // two streams of the library's own -- kernel stores `decide`, the far stream's wait passes, its kernel stores `go`,
   // the other stream's wait passes -- and must have completed within three seconds (the first launch loads code objects).  If not, the mechanism stays off for this
-  // thread (the rehearsal's streams are abandoned, not destroyed: one of them may still be parked).
+  // thread (the rehearsal's streams are released and abandoned).
   {
     hipStream_t probe = nullptr;
     (void)hipGetLastError();  // (a stale error of some earlier call must not be taken for one of these launches')
@@ -438,6 +438,11 @@ static bool async_far_ready(ThreadCtx& c) {
       (void)hipGetLastError();
       fprintf(stderr, "[gsr] stream-side waits did not complete their rehearsal (step %d): far-chain speculation stays on "
                       "the host\n", step);
+      // do not leave a parked stream behind (it would keep the process from exiting): both words to a value that
+      // satisfies every wait, then the streams are abandoned
+      (void)hipMemset(a, 0xFF, 8);
+      (void)hipMemset(b, 0xFF, 8);
+      (void)hipGetLastError();
       return false;
     }
     (void)hipStreamDestroy(probe);
