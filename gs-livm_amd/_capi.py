@@ -62,7 +62,8 @@ EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_byte
            "gsr_last_num_rendered", "gsr_set_binning_capacity_hint", "gsr_speculative_forwards",
            "gsr_speculation_overflows", "gsr_mailbox_slow_path_last", "gsr_set_near_far", "gsr_near_far",
            "gsr_last_near_far", "gsr_set_near_far_hints", "gsr_near_far_forwards", "gsr_set_far_speculation",
-           "gsr_last_far_skipped", "gsr_far_skips", "gsr_far_skip_misses", "gsr_async_far_frames")
+           "gsr_last_far_skipped", "gsr_far_skips", "gsr_far_skip_misses", "gsr_async_far_frames",
+           "gsr_near_budget_scale", "gsr_near_budget_feedback", "gsr_near_far_pause")
 
 
 def lib():
@@ -126,6 +127,12 @@ def lib():
     L.gsr_set_far_speculation.argtypes = [ci]
     L.gsr_last_far_skipped.restype = ci
     L.gsr_last_far_skipped.argtypes = []
+    L.gsr_near_budget_scale.restype = C.c_uint
+    L.gsr_near_budget_scale.argtypes = []
+    L.gsr_near_budget_feedback.restype = C.c_uint
+    L.gsr_near_budget_feedback.argtypes = [C.c_uint, C.c_uint, C.c_uint]
+    L.gsr_near_far_pause.restype = ci
+    L.gsr_near_far_pause.argtypes = [ci]
     for n in ("gsr_far_skips", "gsr_far_skip_misses", "gsr_async_far_frames"):
         getattr(L, n).restype = C.c_ulonglong
         getattr(L, n).argtypes = []

@@ -223,6 +223,10 @@ struct ThreadCtx {
   uint32_t last_near = 0, last_far = 0;
   bool last_was_near_far = false;
   int far_idle_streak = 0;                    // consecutive near/far frames of this thread that left no tile live
+  // adaptive near budget (budget_feedback): the configured entries per tile x near_scale_q8 / 256
+  uint32_t near_scale_q8 = 256;
+  int near_hit_run = 0, near_miss_run = 0;
+  int split_pause = 0;                        // frames for which this thread bins in one chain again (budget_feedback)
   int far_skip_override = -1;                 // gsr_set_far_speculation: -1 auto, 0 never, 1 the next split forward
   bool last_far_skipped = false;
   // asynchronous near/far frames: a second stream for the far chain, three signal words (0 decide, 1 go), a sequence
@@ -466,6 +470,37 @@ static bool peek_word(const ThreadCtx& c, int word, uint32_t ticket, uint32_t* o
 
 static std::atomic<unsigned long long> g_far_skips{0}, g_far_skip_misses{0}, g_async_frames{0};
 
+// Adaptive near budget.  A frame whose near chain leaves quads unfinished pays for a far chain -- the eleven launches, a
+// full depth sort, its instances -- and does not qualify for the far-chain speculation; a budget that is larger than
+// necessary only costs the near chain's extra instances (2 M Gaussians / 1080p: 480 instead of 320 entries per tile
+// +2.6 % of a step; a far chain over 5.7 M instances +38 %).  So every miss whose far chain stays below four times the
+// near chain's instances (beyond that the scene is sparse: no budget finishes its tiles) raises the thread's budget by a
+// quarter of the configured one, up to three times it, and a long run of frames without a far chain (64) takes a
+// sixteenth back, down to the configured budget.  (The same scene after a few dozen optimiser steps, or under the
+// photometric loss, needs 360-480 entries per tile: 1.15 -> 0.91 and 1.04 -> 1.00 ms/step.)  Not while a test hook sets
+// the budget.
+static void budget_feedback(ThreadCtx& c, uint32_t live, uint32_t R_near, uint32_t R_far) {
+  if (c.near_entries_override >= 0) return;
+  if (live == 0u) {
+    c.near_miss_run = 0;
+    if (++c.near_hit_run >= 64 && c.near_scale_q8 > 256u) {
+      c.near_scale_q8 -= 16u;
+      c.near_hit_run = 0;
+    }
+  } else {
+    c.near_hit_run = 0;
+    const bool sparse = (unsigned long long)R_far >= 4ull * (unsigned long long)R_near;
+    if (!sparse) c.near_scale_q8 = c.near_scale_q8 + 64u < 768u ? c.near_scale_q8 + 64u : 768u;
+    // Eight misses in a row that no budget mends (the scale is at its cap, or the scene is sparse): splitting costs
+    // more than it saves -- both chains, a full depth sort, two blends (measured on a scene that had drifted that far:
+    // +5 % over the one-chain frame) -- so the thread bins in one chain for the next 256 frames and then tries again.
+    if (++c.near_miss_run >= 8 && (sparse || c.near_scale_q8 >= 768u)) {
+      c.split_pause = 256;
+      c.near_miss_run = 0;
+    }
+  }
+}
+
 // What an asynchronous frame left open when gsr_forward returned -- did its far chain run, and over how many
 // instances -- is read from the mailbox the next time the thread asks (never waited for).
 static void lazy_resolve(ThreadCtx& c) {
@@ -476,6 +511,7 @@ static void lazy_resolve(ThreadCtx& c) {
   c.lazy_pending = false;
   c.last_far = far;
   c.last_far_skipped = live == 0u;
+  budget_feedback(c, live, c.last_near, far);
   c.recent_far[c.recent_far_pos] = far;
   c.recent_far_pos = (c.recent_far_pos + 1) & 3;
   c.have_far = true;
@@ -690,10 +726,17 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   // are shorter.  gsr_set_reference_rects(1) frames are never split: their lists are the reference's, whole.
   static const long env_near_entries = getenv("GSR_NEAR_ENTRIES") ? atol(getenv("GSR_NEAR_ENTRIES")) : 320;
   const int tiles_n = fp.gx * fp.gy;
-  const long long near_entries = c.near_entries_override >= 0 ? c.near_entries_override : env_near_entries;
+  const long long near_entries = c.near_entries_override >= 0
+                                     ? c.near_entries_override
+                                     : (env_near_entries * (long long)c.near_scale_q8 + 255) / 256;  // (budget_feedback)
   const unsigned long long budget64 = (unsigned long long)tiles_n * (unsigned long long)near_entries;
+  bool split_paused = false;
+  if (c.split_pause > 0 && c.near_entries_override < 0) {  // (budget_feedback: this thread's splits kept missing)
+    c.split_pause--;
+    split_paused = true;
+  }
   const bool near_far = speculate && near_far_flag().load() && !fp.ref_rects && near_entries > 0 &&
-                        budget64 < 0x20000000ull &&
+                        budget64 < 0x20000000ull && !split_paused &&
                         (c.near_entries_override >= 0 || (unsigned long long)hint >= 4ull * budget64);  // (hook: always)
   // Far-chain speculation (see the near/far branch below): after two split frames in a row that left no quad
   // unfinished (or when the test hook asks) the thread's next split frame expects its far chain to stay idle.
@@ -852,6 +895,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
           if ((rc = wait_num_rendered(c, stream, &R_far, 1)) != GSR_OK) return rc;
         }
         c.far_idle_streak = live == 0u ? c.far_idle_streak + 1 : 0;
+        budget_feedback(c, live, R_near, R_far);
       }
       if (host_trace)
         fprintf(stderr, "[gsr] near/far forward: capacity %u + %u, near %u, far %u of %u instances, %u unfinished quads%s, "
@@ -951,6 +995,19 @@ int gsr_last_far_skipped(void) {
   return g_ctx.last_far_skipped ? 1 : 0;
 }
 unsigned long long gsr_async_far_frames(void) { return g_async_frames.load(); }
+unsigned gsr_near_budget_scale(void) {
+  lazy_resolve(g_ctx);
+  return g_ctx.near_scale_q8;
+}
+unsigned gsr_near_budget_feedback(unsigned unfinished_quads, unsigned near_instances, unsigned far_instances) {
+  budget_feedback(g_ctx, unfinished_quads, near_instances, far_instances);
+  return g_ctx.near_scale_q8;
+}
+int gsr_near_far_pause(int frames) {
+  const int prev = g_ctx.split_pause;
+  if (frames >= 0) g_ctx.split_pause = frames;
+  return prev;
+}
 unsigned long long gsr_far_skips(void) { return g_far_skips.load(); }
 unsigned long long gsr_far_skip_misses(void) { return g_far_skip_misses.load(); }
 long long gsr_set_binning_capacity_hint(long long capacity) {

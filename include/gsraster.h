@@ -134,6 +134,19 @@ int gsr_last_far_skipped(void);
 unsigned long long gsr_far_skips(void);       /* process-wide counters */
 unsigned long long gsr_far_skip_misses(void);
 unsigned long long gsr_async_far_frames(void);
+/* Adaptive near budget (calling thread).  The budget of a split frame is GSR_NEAR_ENTRIES (320) list entries per tile
+ * times scale / 256.  A frame whose far chain ran, over less than four times the near chain's instances, raises the
+ * scale by 64 (a quarter of the configured budget), up to 768; sixty-four frames in a row without a far chain lower it
+ * by 16, down to 256.  gsr_near_budget_scale returns the current scale; gsr_near_budget_feedback (test hook) feeds the
+ * outcome of a frame -- unfinished quads after the near chain, near and far instance counts -- to the rule as a forward
+ * does and returns the scale after it.  The rule rests while gsr_set_near_far_hints sets the budget. */
+unsigned gsr_near_budget_scale(void);
+unsigned gsr_near_budget_feedback(unsigned unfinished_quads, unsigned near_instances, unsigned far_instances);
+/* Eight such misses in a row that no budget mends (the scale is at its cap, or the far chain is at least four times
+ * the near chain: a sparse scene) pause the splitting: the thread bins its next 256 frames in one chain and then tries
+ * again.  gsr_near_far_pause(frames): returns the frames left of the calling thread's pause and, if frames >= 0, sets
+ * them (0 ends a pause). */
+int gsr_near_far_pause(int frames);
 
 /* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:53-88,
  * rasterizer_impl.cu:346-457).  geom/binning/image blobs are the ones the forward

@@ -73,3 +73,50 @@ def test_argument_errors_are_reported_not_crashed():
     assert rc == -1
     assert L.gsr_mark_visible(-3, null, null, null, null, null) == -1
     assert L.gsr_mark_visible(0, null, null, null, null, null) == 0
+
+
+def test_adaptive_near_budget_rule():
+    """include/gsraster.h, "Adaptive near budget": host-side rule, no device involved."""
+    L = G.lib()
+    fb = L.gsr_near_budget_feedback
+    assert L.gsr_near_budget_scale() == 256
+    assert fb(10, 1000, 4000) == 256             # a miss over a HUGE remainder (a sparse scene): no budget helps
+    assert fb(10, 1000, 3999) == 320             # any other miss: + a quarter of the configured budget
+    for k in range(6):
+        s = fb(3, 1000, 10)
+    assert s == 704 and L.gsr_near_far_pause(-1) == 0
+    s = fb(3, 1000, 10)
+    assert s == 768                              # capped at three times the configured budget ...
+    assert L.gsr_near_far_pause(-1) == 256       # ... and this was the eighth miss in a row: splitting pauses
+    assert L.gsr_near_far_pause(0) == 256
+    for k in range(63):
+        assert fb(0, 1000, 0) == 768             # hits ...
+    assert fb(0, 1000, 0) == 752                 # ... sixty-four in a row: a sixteenth back
+    assert fb(5, 1000, 10) == 768                # a miss restarts the run (and stays within the cap)
+    for k in range(64 * 40):
+        s = fb(0, 1000, 0)
+    assert s == 256                              # and never below the configured budget
+    for k in range(200):
+        assert fb(0, 1000, 0) == 256
+    # misses that no budget mends pause the splitting: a sparse scene at once ...
+    assert L.gsr_near_far_pause(-1) == 0
+    for k in range(7):
+        fb(10, 1000, 9000)
+    assert L.gsr_near_far_pause(-1) == 0
+    fb(10, 1000, 9000)
+    assert L.gsr_near_far_pause(-1) == 256 and L.gsr_near_budget_scale() == 256
+    assert L.gsr_near_far_pause(0) == 256 and L.gsr_near_far_pause(-1) == 0
+    # ... a dense one with the eighth miss in a row, by which the budget has reached its cap
+    for k in range(7):
+        fb(10, 1000, 500)
+    assert L.gsr_near_budget_scale() == 704 and L.gsr_near_far_pause(-1) == 0
+    fb(10, 1000, 500)
+    assert L.gsr_near_budget_scale() == 768 and L.gsr_near_far_pause(-1) == 256
+    L.gsr_near_far_pause(0)
+    fb(0, 1000, 0)                               # a hit ends the run of misses
+    for k in range(7):
+        fb(10, 1000, 500)
+    assert L.gsr_near_far_pause(-1) == 0
+    for k in range(64 * 40):
+        fb(0, 1000, 0)
+    assert L.gsr_near_budget_scale() == 256

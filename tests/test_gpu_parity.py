@@ -421,17 +421,24 @@ def test_two_host_threads_render_concurrently(gpu_device):
     g_ref = hip_backward(sc, t0, one, dcol, dacc, dev, debug=False)
     torch.cuda.synchronize()
     errors, skipped = [], []
+    t_in = to_dev(sc, dev)
+
+    def forward():  # (not hip_forward: it flips the PROCESS-WIDE binning switches around the call)
+        return G.rasterize_forward(t_in["bg"], t_in["means3D"], t_in["colors_precomp"], t_in["opacities"], t_in["scales"],
+                                   t_in["rotations"], 1.0, t_in["cov3D_precomp"], t_in["viewmatrix"], t_in["projmatrix"],
+                                   sc["tanfovx"], sc["tanfovy"], sc["H"], sc["W"], t_in["shs"], sc["sh_degree"],
+                                   t_in["campos"], False, False)
 
     def worker(k):
         try:
             stream = torch.cuda.Stream(device=dev)
             with torch.cuda.stream(stream):
                 G.set_binning_capacity_hint(0)
-                hip_forward(sc, dev, debug=False)                   # this thread's first forward is synchronous
+                forward()                                           # this thread's first forward is synchronous
                 for it in range(8):
                     G.set_near_far_hints(200, None)
                     G.set_far_speculation(True)
-                    t, fwd = hip_forward(sc, dev, debug=False, near_far=True)
+                    t, fwd = t_in, forward()
                     g = hip_backward(sc, t, fwd, dcol, dacc, dev, debug=False)
                     for i, (x, y) in enumerate(zip(one[1:5], fwd[1:5])):
                         assert torch.equal(x, y), (k, it, i)
@@ -445,10 +452,15 @@ def test_two_host_threads_render_concurrently(gpu_device):
             errors.append((k, repr(e)))
 
     threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
-    for th in threads:
-        th.start()
-    for th in threads:
-        th.join(timeout=120)
+    prev_nf, prev_rr = G.set_near_far(True), G.set_reference_rects(False)
+    try:
+        for th in threads:
+            th.start()
+        for th in threads:
+            th.join(timeout=120)
+    finally:
+        G.set_near_far(prev_nf)
+        G.set_reference_rects(prev_rr)
     assert not any(th.is_alive() for th in threads), "a rendering thread hangs"
     assert not errors, errors
     assert len(skipped) == 16 and all(skipped)                      # every frame completed without a far chain
