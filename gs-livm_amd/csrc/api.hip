@@ -715,7 +715,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   int key = 0;  // what the caller passes back to gsr_backward: the capacity the binning blob was carved for
   c.last_was_near_far = false;
   // Near/far frame (speculative forwards in the default binning mode, when the predicted instance count is at least
-  // four times the near budget): the tiles' lists are depth-ordered and a pixel stops reading its list once its
+  // three times the near budget): the tiles' lists are depth-ordered and a pixel stops reading its list once its
   // transmittance falls below 1e-4 (forward.cu:380-383) -- at 2 M Gaussians / 1080p every tile is finished after
   // ~3 % of its list, and emitting, sorting and ranging the other 97 % is most of the forward.  So the frame is binned
   // in two chains over the Gaussians in depth order: the NEAR chain takes Gaussians until they fill a budget of
@@ -735,9 +735,13 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     c.split_pause--;
     split_paused = true;
   }
+  // (three times: BASELINE C2 -- 500 k Gaussians at 1280x720, 3.6 M instances, 3.1 budgets -- bins 1.15 M of them and its
+  // forward goes 0.31 -> 0.245 ms; at 1.5 budgets, the 640x512 shape, a split saves nothing.  In quarters:)
+  static const unsigned long long env_ratio_q2 =
+      getenv("GSR_NEAR_FAR_MIN_RATIO_Q2") ? strtoull(getenv("GSR_NEAR_FAR_MIN_RATIO_Q2"), nullptr, 10) : 12ull;
   const bool near_far = speculate && near_far_flag().load() && !fp.ref_rects && near_entries > 0 &&
                         budget64 < 0x20000000ull && !split_paused &&
-                        (c.near_entries_override >= 0 || (unsigned long long)hint >= 4ull * budget64);  // (hook: always)
+                        (c.near_entries_override >= 0 || 4ull * (unsigned long long)hint >= env_ratio_q2 * budget64);  // (hook: always)
   // Far-chain speculation (see the near/far branch below): after two split frames in a row that left no quad
   // unfinished (or when the test hook asks) the thread's next split frame expects its far chain to stay idle.
   const bool speculate_far = near_far && (c.far_skip_override >= 0 ? c.far_skip_override == 1 : c.far_idle_streak >= 2);
