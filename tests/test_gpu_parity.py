@@ -479,6 +479,15 @@ def test_c3_near_far(c3, gpu_device):
         G.set_far_speculation(None)
 
 
+def test_c2_near_far(gpu_device):
+    """BASELINE C2 (500 k Gaussians, 1280x720: 3.1 near budgets of instances) is a near/far frame by the library's own
+    rule -- no hook sets the budget -- and bit-identical to its one-chain frame; the near chain bins a third of it."""
+    P, W, H, seed = S.CONFIGS["C2"]
+    sc = S.make_scene(P, W, H, seed)
+    st = _check_near_far_against_one_chain(sc, gpu_device, None)
+    assert st["live_tiles"] == 0 and st["far"] == 0 and st["near"] < st["one"] // 2
+
+
 def test_empty_input_is_a_noop(gpu_device):
     """rasterize_points.cu:92-93,183: P == 0 -> num_rendered 0, zero images, empty grads."""
     sc = S.make_scene(0, 64, 48, 1)
