@@ -30,7 +30,7 @@ UNITS = {
     # into mov_dpp + pk_add: measured 9 % slower on k_blend_backward, so it is off for the blend kernels.
     "render.hip": ["-ffp-contract=fast", "-fno-slp-vectorize"] + os.environ.get("GSR_EXTRA_RENDER_FLAGS", "").split(),
     "optimizer.hip": [],
-    "loss.hip": [],
+    "loss.hip": ["-fno-slp-vectorize"],  # (packing the 11-tap sums costs more moves than it saves: 944 -> 732 VALU in the backward)
     "growth.hip": [],
     "api.hip": [],
 }

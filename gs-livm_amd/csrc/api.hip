@@ -1144,6 +1144,8 @@ int gsr_photometric_loss(int channels, int height, int width, const float* img, 
                          char* workspace, size_t workspace_bytes, void* stream_) {
   g_err[0] = 0;
   if (channels <= 0 || height <= 0 || width <= 0) return fail(GSR_ERR_INVALID_ARGUMENT, "bad image shape");
+  if ((unsigned long long)height * (unsigned long long)width >= 0x7fffffffull)  // (32-bit offsets inside a plane)
+    return fail(GSR_ERR_INVALID_ARGUMENT, "image plane too large");
   if (!img || !gt || !window11_host || !loss_out3 || !workspace) return fail(GSR_ERR_INVALID_ARGUMENT, "null pointer");
   if (workspace_bytes < loss_workspace_bytes(channels, height, width))
     return fail(GSR_ERR_INVALID_ARGUMENT, "workspace too small: need %zu bytes",

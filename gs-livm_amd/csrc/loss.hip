@@ -7,8 +7,9 @@
 // src/liw/lioOptimization.cpp:1705-1710 with lambda = lambda_dssim (config/basic_common.yaml:63).  The
 // reference runs five grouped 11x11 conv2d + ~15 elementwise kernels forward and their autograd backward per
 // view; here:
-//   k_loss_forward   one pass: separable 11-tap window over (x, y, x^2, y^2, xy) in LDS, SSIM map, the three
-//                    per-pixel derivative maps the backward needs, per-workgroup partial sums of |x-y| and SSIM
+//   k_loss_forward   one pass: separable 11-tap window over (x, y, x^2 + y^2, xy) -- vertical pass in registers
+//                    straight from coalesced loads, horizontal pass through LDS --, SSIM map, the three per-pixel
+//                    derivative maps the backward needs, per-workgroup partial sums of |x-y| and SSIM
 //   k_loss_finalize  fixed-order sum of the partials -> {loss, l1, ssim}   (deterministic: no float atomics)
 //   k_loss_backward  dL/dimg = (1-lambda)/N * sign(x-y) - lambda/N * [convT(A) + 2x convT(B) + y convT(C)]
 // The window is whatever 1-D kernel the caller passes (the 2-D window of the reference is its outer product,
@@ -21,100 +22,140 @@ namespace gsr {
 
 constexpr int LW_ = 11;          // window taps
 constexpr int LR_ = LW_ / 2;     // halo
-constexpr int LTX_ = 32, LTY_ = 16;                      // output tile of one 256-thread workgroup
-constexpr int LHX_ = LTX_ + 2 * LR_, LHY_ = LTY_ + 2 * LR_;  // 42 x 26 input tile
+// Work unit of one 256-thread workgroup: 54 x 32 outputs.  Wave w owns the 8 output rows 8w .. 8w+7, lane l the input
+// column x0 - 5 + l (64 columns = 54 outputs + the halo), so every global load of the vertical pass is one coalesced
+// 256-byte row segment and the pass runs in registers straight from those loads (18 rows -> 8 outputs per moment, taps
+// in the order of a plain 11-tap sum); its results cross the workgroup's ONE barrier through LDS and the horizontal pass
+// is register-blocked seven outputs to a thread (17 staged values per moment).
+constexpr int LTX_ = 54, LTY_ = 32;
+constexpr int LSEG_ = 8;                    // output rows per wave
+constexpr int LIN_ = LSEG_ + 2 * LR_;       // 18 input rows per wave
+constexpr int LHO_ = 7;                     // horizontal pass: outputs per thread (8 threads x 7 >= 54)
+constexpr int LFLAT_ = (LTX_ * LTY_ + 255) / 256;  // 7 elements per thread in the tile's flattened order
+constexpr int LSTRIDE_ = 72;                // LDS row stride: (8 r + 7 g + k) mod 64 is conflict-free over a wave's 8 x 8
 constexpr float SSIM_C1 = 0.01f * 0.01f, SSIM_C2 = 0.03f * 0.03f;  // loss_utils.cuh:8-9
 
 struct LossWindow { float w[LW_]; };
 
-// Both passes are register-blocked: a thread of the horizontal pass produces 4 adjacent outputs of one row from
-// 14 staged inputs (instead of 4 x 11 reads), a thread of the vertical pass 2 vertically adjacent outputs from
-// 12 filtered values per moment -- the window is walked in the same tap order as a plain 11-tap sum, so the
-// arithmetic is unchanged while LDS traffic per pixel drops ~2.5x and the halo (42 x 26 for 32 x 16) ~1.25x.
-
-// mu(q) = sum_k w[k] * f(q + k - 5)   (cross-correlation, zero padded): what conv2d computes
+// mu(q) = sum_k w[k] * f(q + k - 5)   (cross-correlation, zero padded): what conv2d computes.  SSIM needs the two
+// variances only through their sum (d2 = sigma1^2 + sigma2^2 + C2), so four windowed moments are carried, not five:
+// E[x], E[y], E[x^2 + y^2], E[xy].
 __global__ __launch_bounds__(256) void k_loss_forward(const int C, const int H, const int W,
                                                       const float* __restrict__ img, const float* __restrict__ gt,
                                                       const LossWindow win, float* __restrict__ mapA,
                                                       float* __restrict__ mapB, float* __restrict__ mapC,
                                                       float* __restrict__ partials) {
-  __shared__ float sx[LHY_][LHX_ + 1], sy[LHY_][LHX_ + 1];
-  __shared__ float h[5][LHY_][LTX_ + 1];  // horizontally filtered rows
+  __shared__ float hv[4][LTY_][LSTRIDE_];  // vertically filtered moments
   __shared__ float red[2][4];
   const int c = blockIdx.z;
   const int x0 = blockIdx.x * LTX_, y0 = blockIdx.y * LTY_;
-  const float* X = img + (size_t)c * H * W;
-  const float* Y = gt + (size_t)c * H * W;
-  {  // all of a thread's halo loads are issued before the first one is consumed (one round trip, not five)
-    constexpr int NI = (LHY_ * LHX_ + 255) / 256;
-    float vx[NI], vy[NI];
-#pragma unroll
-    for (int it = 0; it < NI; it++) {
-      const int i = threadIdx.x + 256 * it, r = i / LHX_, cc = i % LHX_;
-      const int gy = y0 + r - LR_, gx = x0 + cc - LR_;
-      const bool in = i < LHY_ * LHX_ && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      vx[it] = in ? X[(size_t)gy * W + gx] : 0.f;
-      vy[it] = in ? Y[(size_t)gy * W + gx] : 0.f;
-    }
-#pragma unroll
-    for (int it = 0; it < NI; it++) {
-      const int i = threadIdx.x + 256 * it, r = i / LHX_, cc = i % LHX_;
-      if (i < LHY_ * LHX_) { sx[r][cc] = vx[it]; sy[r][cc] = vy[it]; }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < LHY_ * (LTX_ / 4)) {  // 26 rows x 8 groups of 4 outputs
-    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
-    float xv[LW_ + 3], yv[LW_ + 3];
-#pragma unroll
-    for (int k = 0; k < LW_ + 3; k++) { xv[k] = sx[r][c0 + k]; yv[k] = sy[r][c0 + k]; }
-#pragma unroll
-    for (int o = 0; o < 4; o++) {
-      float a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0;
-#pragma unroll
-      for (int k = 0; k < LW_; k++) {
-        const float xq = xv[o + k], yq = yv[o + k], wk = win.w[k];
-        a0 += wk * xq; a1 += wk * yq; a2 += wk * xq * xq; a3 += wk * yq * yq; a4 += wk * xq * yq;
-      }
-      h[0][r][c0 + o] = a0; h[1][r][c0 + o] = a1; h[2][r][c0 + o] = a2; h[3][r][c0 + o] = a3; h[4][r][c0 + o] = a4;
-    }
-  }
-  __syncthreads();
+  const size_t plane = (size_t)c * H * W;
+  const float* X = img + plane;
+  const float* Y = gt + plane;
+  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
   float l1 = 0.f, ss = 0.f;
-  const int tx = threadIdx.x & 31, ty0 = (threadIdx.x >> 5) * 2;  // two vertically adjacent outputs
-  float m[5][2];
+  {
+    const int gx = x0 - LR_ + lane;
+    const bool col_in = gx >= 0 && gx < W;
+    const int gxc = min(max(gx, 0), W - 1);
+    float vx[LIN_], vy[LIN_];
 #pragma unroll
-  for (int q = 0; q < 5; q++) {
-    float col[LW_ + 1];
+    for (int i = 0; i < LIN_; i++) {  // all 36 loads are in flight before the first is consumed: clamped addresses,
+      const int gy = y0 + LSEG_ * seg - LR_ + i;  // unconditional loads, zero padding by select (no branch per load)
+      const int off = min(max(gy, 0), H - 1) * W + gxc;
+      const float a = X[off], b = Y[off];
+      const bool in = col_in && gy >= 0 && gy < H;
+      vx[i] = in ? a : 0.f;
+      vy[i] = in ? b : 0.f;
+    }
+    float acc[LSEG_][4];
 #pragma unroll
-    for (int k = 0; k < LW_ + 1; k++) col[k] = h[q][ty0 + k][tx];
-    float o0 = 0, o1 = 0;
+    for (int o = 0; o < LSEG_; o++) acc[o][0] = acc[o][1] = acc[o][2] = acc[o][3] = 0.f;
 #pragma unroll
-    for (int k = 0; k < LW_; k++) { o0 += win.w[k] * col[k]; o1 += win.w[k] * col[k + 1]; }
-    m[q][0] = o0; m[q][1] = o1;
+    for (int i = 0; i < LIN_; i++) {
+      const float x = vx[i], y = vy[i];
+      const float p2 = __builtin_fmaf(y, y, x * x), p3 = x * y;
+#pragma unroll
+      for (int o = 0; o < LSEG_; o++) {
+        const int k = i - o;
+        if (k >= 0 && k < LW_) {
+          const float wk = win.w[k];
+          acc[o][0] += wk * x; acc[o][1] += wk * y; acc[o][2] += wk * p2; acc[o][3] += wk * p3;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < LSEG_; o++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) hv[q][LSEG_ * seg + o][lane] = acc[o][q];
+    }
+    if (lane >= LR_ && lane < LR_ + LTX_ && col_in) {  // the L1 term of this thread's own eight output pixels
+#pragma unroll
+      for (int o = 0; o < LSEG_; o++)
+        if (y0 + LSEG_ * seg + o < H) l1 += fabsf(vx[o + LR_] - vy[o + LR_]);
+    }
   }
+  __syncthreads();
+  {
+    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * LHO_;
+    float m[4][LHO_];
 #pragma unroll
-  for (int o = 0; o < 2; o++) {
-    const int gx = x0 + tx, gy = y0 + ty0 + o;
-    if (gx < W && gy < H) {
-      const float mu1 = m[0][o], mu2 = m[1][o], e11 = m[2][o], e22 = m[3][o], e12 = m[4][o];
-      const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
-      const float s1 = e11 - mu1_sq, s2 = e22 - mu2_sq, s12 = e12 - mu12;
-      const float n1 = 2.f * mu12 + SSIM_C1, n2 = 2.f * s12 + SSIM_C2;
-      const float d1 = mu1_sq + mu2_sq + SSIM_C1, d2 = s1 + s2 + SSIM_C2;
-      const float inv = 1.0f / (d1 * d2);
-      const float sv = n1 * n2 * inv;
-      // partials of s w.r.t. (mu1, sigma1_sq, sigma12) at fixed img2
-      const float ds_dmu1 = (2.f * mu2 * n2 * d1 - 2.f * mu1 * n1 * n2) * inv / d1;  // d/dmu1 of n1/d1 times n2/d2
-      const float ds_ds1 = -sv / d2;
-      const float ds_ds12 = 2.f * n1 * inv;
-      // total derivative through sigma1_sq = E[x^2] - mu1^2 and sigma12 = E[xy] - mu1*mu2:
-      const size_t oidx = ((size_t)c * H + gy) * W + gx;
-      mapA[oidx] = ds_dmu1 - 2.f * mu1 * ds_ds1 - mu2 * ds_ds12;
-      mapB[oidx] = ds_ds1;
-      mapC[oidx] = ds_ds12;
-      ss += sv;
-      l1 += fabsf(sx[ty0 + o + LR_][tx + LR_] - sy[ty0 + o + LR_][tx + LR_]);
+    for (int q = 0; q < 4; q++) {
+      float v[LHO_ + LW_ - 1];
+#pragma unroll
+      for (int k = 0; k < LHO_ + LW_ - 1; k++) v[k] = hv[q][r][c0 + k];  // (the last group reads into the row padding)
+#pragma unroll
+      for (int o = 0; o < LHO_; o++) {
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < LW_; k++) a += win.w[k] * v[o + k];
+        m[q][o] = a;
+      }
+    }
+    const int gy = y0 + r;
+    float oa[LHO_], ob[LHO_], oc[LHO_];
+#pragma unroll
+    for (int o = 0; o < LHO_; o++) {
+      const int gx = x0 + c0 + o;
+      oa[o] = ob[o] = oc[o] = 0.f;
+      if (c0 + o < LTX_ && gx < W && gy < H) {
+        const float mu1 = m[0][o], mu2 = m[1][o], e_sum = m[2][o], e12 = m[3][o];
+        const float mu1_sq = mu1 * mu1, mu2_sq = mu2 * mu2, mu12 = mu1 * mu2;
+        const float s12 = e12 - mu12;
+        const float n1 = 2.f * mu12 + SSIM_C1, n2 = 2.f * s12 + SSIM_C2;
+        const float d1 = mu1_sq + mu2_sq + SSIM_C1, d2 = (e_sum - mu1_sq - mu2_sq) + SSIM_C2;
+        const float r1 = __builtin_amdgcn_rcpf(d1), r2 = __builtin_amdgcn_rcpf(d2);  // (1 ulp; d1, d2 >= C1, C2 > 0 up to rounding)
+        const float inv = r1 * r2;
+        const float sv = n1 * n2 * inv;
+        // partials of s w.r.t. (mu1, sigma1_sq, sigma12) at fixed img2
+        const float ds_dmu1 = 2.f * n2 * (mu2 * d1 - mu1 * n1) * inv * r1;  // d/dmu1 of n1/d1 times n2/d2
+        const float ds_ds1 = -sv * r2;
+        const float ds_ds12 = 2.f * n1 * inv;
+        // total derivative through sigma1_sq = E[x^2] - mu1^2 and sigma12 = E[xy] - mu1*mu2:
+        oa[o] = ds_dmu1 - 2.f * mu1 * ds_ds1 - mu2 * ds_ds12;
+        ob[o] = ds_ds1;
+        oc[o] = ds_ds12;
+        ss += sv;
+      }
+    }
+    // A thread's seven outputs are adjacent in a row: stored from here, a wave's store would be 64 separate 4-byte
+    // accesses (measured: the kernel was bound by them, not by its arithmetic).  The maps change hands through LDS
+    // and leave in the flattened order of the tile, 54-float row segments to consecutive lanes.
+    __syncthreads();  // (everyone has read hv)
+#pragma unroll
+    for (int o = 0; o < LHO_; o++) { hv[0][r][c0 + o] = oa[o]; hv[1][r][c0 + o] = ob[o]; hv[2][r][c0 + o] = oc[o]; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < LFLAT_; it++) {
+    const int e = it * 256 + (int)threadIdx.x;
+    const int row = e / LTX_, col = e - row * LTX_;
+    const int gx = x0 + col, gy = y0 + row;
+    if (e < LTX_ * LTY_ && gx < W && gy < H) {
+      const size_t oidx = plane + (size_t)gy * W + gx;
+      mapA[oidx] = hv[0][row][col];
+      mapB[oidx] = hv[1][row][col];
+      mapC[oidx] = hv[2][row][col];
     }
   }
   // fixed-order workgroup reduction -> one partial pair per workgroup
@@ -157,84 +198,100 @@ __global__ __launch_bounds__(1024) void k_loss_finalize(const float* __restrict_
 }
 
 // dL/dx(p) = (1-lambda)/N sign(x-y) - lambda/N * sum_q w(p - q + 5) * [A(q) + 2 x(p) B(q) + y(p) C(q)]
-// i.e. the transposed correlation: taps are read flipped.
+// i.e. the transposed correlation: taps are read flipped.  Same work unit and passes as the forward, over the three
+// derivative maps.
 __global__ __launch_bounds__(256) void k_loss_backward(const int C, const int H, const int W,
                                                        const float* __restrict__ img, const float* __restrict__ gt,
                                                        const LossWindow win, const float* __restrict__ mapA,
                                                        const float* __restrict__ mapB, const float* __restrict__ mapC,
                                                        const float inv_n, const float lambda,
                                                        float* __restrict__ dL_dimg) {
-  __shared__ float s[3][LHY_][LHX_ + 1];
-  __shared__ float h[3][LHY_][LTX_ + 1];
+  __shared__ float hv[3][LTY_][LSTRIDE_];
   const int c = blockIdx.z;
   const int x0 = blockIdx.x * LTX_, y0 = blockIdx.y * LTY_;
   const size_t plane = (size_t)c * H * W;
-  const int tx = threadIdx.x & 31, ty0 = (threadIdx.x >> 5) * 2;
-  float px[2], py[2];  // this thread's two output pixels of img / gt, requested together with the halo
+  const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+  const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * LHO_;
+  float px[LFLAT_], py[LFLAT_];  // img / gt at this thread's output pixels (flattened order), requested with the maps
   {
-    constexpr int NI = (LHY_ * LHX_ + 255) / 256;
-    float va[NI], vb[NI], vc[NI];
+    const int gx = x0 - LR_ + lane;
+    const bool col_in = gx >= 0 && gx < W;
+    const int gxc = min(max(gx, 0), W - 1);
+    const float* MA = mapA + plane;
+    const float* MB = mapB + plane;
+    const float* MC = mapC + plane;
+    float va[LIN_], vb[LIN_], vc[LIN_];
 #pragma unroll
-    for (int it = 0; it < NI; it++) {
-      const int i = threadIdx.x + 256 * it, r = i / LHX_, cc = i % LHX_;
-      const int gy = y0 + r - LR_, gx = x0 + cc - LR_;
-      const bool in = i < LHY_ * LHX_ && gy >= 0 && gy < H && gx >= 0 && gx < W;
-      const size_t o = plane + (size_t)gy * W + gx;
-      va[it] = in ? mapA[o] : 0.f;
-      vb[it] = in ? mapB[o] : 0.f;
-      vc[it] = in ? mapC[o] : 0.f;
+    for (int i = 0; i < LIN_; i++) {  // (clamped addresses, unconditional loads, zero padding by select)
+      const int gy = y0 + LSEG_ * seg - LR_ + i;
+      const int off = min(max(gy, 0), H - 1) * W + gxc;
+      const float a = MA[off], b = MB[off], cc = MC[off];
+      const bool in = col_in && gy >= 0 && gy < H;
+      va[i] = in ? a : 0.f;
+      vb[i] = in ? b : 0.f;
+      vc[i] = in ? cc : 0.f;
     }
 #pragma unroll
-    for (int o = 0; o < 2; o++) {
-      const int gx = x0 + tx, gy = y0 + ty0 + o;
-      const bool in = gx < W && gy < H;
-      px[o] = in ? img[plane + (size_t)gy * W + gx] : 0.f;
-      py[o] = in ? gt[plane + (size_t)gy * W + gx] : 0.f;
+    for (int it = 0; it < LFLAT_; it++) {  // (pixels outside the image or the tile are never stored: any valid address)
+      const int e = it * 256 + (int)threadIdx.x;
+      const int row = e / LTX_, col = e - row * LTX_;
+      const int off = min(y0 + row, H - 1) * W + min(x0 + col, W - 1);
+      px[it] = img[plane + off];
+      py[it] = gt[plane + off];
     }
+    float acc[LSEG_][3];
 #pragma unroll
-    for (int it = 0; it < NI; it++) {
-      const int i = threadIdx.x + 256 * it, r = i / LHX_, cc = i % LHX_;
-      if (i < LHY_ * LHX_) { s[0][r][cc] = va[it]; s[1][r][cc] = vb[it]; s[2][r][cc] = vc[it]; }
-    }
-  }
-  __syncthreads();
-  if (threadIdx.x < LHY_ * (LTX_ / 4)) {  // register-blocked as the forward: 4 adjacent outputs per thread
-    const int r = threadIdx.x >> 3, c0 = (threadIdx.x & 7) * 4;
+    for (int o = 0; o < LSEG_; o++) acc[o][0] = acc[o][1] = acc[o][2] = 0.f;
 #pragma unroll
-    for (int q = 0; q < 3; q++) {
-      float v[LW_ + 3];
+    for (int i = 0; i < LIN_; i++) {
 #pragma unroll
-      for (int k = 0; k < LW_ + 3; k++) v[k] = s[q][r][c0 + k];
-#pragma unroll
-      for (int o = 0; o < 4; o++) {
-        float a = 0;
-#pragma unroll
-        for (int k = 0; k < LW_; k++) a += win.w[LW_ - 1 - k] * v[o + k];  // flipped taps
-        h[q][r][c0 + o] = a;
+      for (int o = 0; o < LSEG_; o++) {
+        const int k = i - o;
+        if (k >= 0 && k < LW_) {
+          const float wk = win.w[LW_ - 1 - k];  // flipped taps
+          acc[o][0] += wk * va[i]; acc[o][1] += wk * vb[i]; acc[o][2] += wk * vc[i];
+        }
       }
     }
+#pragma unroll
+    for (int o = 0; o < LSEG_; o++) {
+#pragma unroll
+      for (int q = 0; q < 3; q++) hv[q][LSEG_ * seg + o][lane] = acc[o][q];
+    }
   }
   __syncthreads();
-  float t[3][2];
+  float t[3][LHO_];
 #pragma unroll
   for (int q = 0; q < 3; q++) {
-    float col[LW_ + 1];
+    float v[LHO_ + LW_ - 1];
 #pragma unroll
-    for (int k = 0; k < LW_ + 1; k++) col[k] = h[q][ty0 + k][tx];
-    float o0 = 0, o1 = 0;
+    for (int k = 0; k < LHO_ + LW_ - 1; k++) v[k] = hv[q][r][c0 + k];
 #pragma unroll
-    for (int k = 0; k < LW_; k++) { o0 += win.w[LW_ - 1 - k] * col[k]; o1 += win.w[LW_ - 1 - k] * col[k + 1]; }
-    t[q][0] = o0; t[q][1] = o1;
+    for (int o = 0; o < LHO_; o++) {
+      float a = 0.f;
+#pragma unroll
+      for (int k = 0; k < LW_; k++) a += win.w[LW_ - 1 - k] * v[o + k];
+      t[q][o] = a;
+    }
   }
+  // the filtered maps change hands through LDS (as the forward's outputs do): the image is read and the gradient
+  // written in the flattened order of the tile, 54-float row segments to consecutive lanes
+  __syncthreads();  // (everyone has read hv)
 #pragma unroll
-  for (int o = 0; o < 2; o++) {
-    const int gx = x0 + tx, gy = y0 + ty0 + o;
-    if (gx < W && gy < H) {
-      const size_t oi = plane + (size_t)gy * W + gx;
-      const float x = px[o], y = py[o];
+  for (int o = 0; o < LHO_; o++) { hv[0][r][c0 + o] = t[0][o]; hv[1][r][c0 + o] = t[1][o]; hv[2][r][c0 + o] = t[2][o]; }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < LFLAT_; it++) {
+    const int e = it * 256 + (int)threadIdx.x;
+    const int row = e / LTX_, col = e - row * LTX_;
+    const int gx = x0 + col, gy = y0 + row;
+    if (e < LTX_ * LTY_ && gx < W && gy < H) {
+      const float x = px[it], y = py[it];
       const float d = x - y;
       const float sgn = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);  // torch: abs'(0) = 0
-      dL_dimg[oi] = (1.f - lambda) * inv_n * sgn - lambda * inv_n * (t[0][o] + 2.f * x * t[1][o] + y * t[2][o]);
+      dL_dimg[plane + (size_t)gy * W + gx] =
+          (1.f - lambda) * inv_n * sgn -
+          lambda * inv_n * (hv[0][row][col] + 2.f * x * hv[1][row][col] + y * hv[2][row][col]);
     }
   }
 }
@@ -262,14 +319,14 @@ hipError_t launch_photometric_loss(int C, int H, int W, const float* img, const 
     ProfScope ps(K_LOSS_FWD, s);
     hipLaunchKernelGGL(k_loss_forward, grid, dim3(256), 0, s, C, H, W, img, gt, win, mapA, mapB, mapC, partials);
   }
-  {
-    ProfScope ps(K_LOSS_FINALIZE, s);
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, partials, nblocks, inv_n, lambda, loss_out3);
-  }
-  if (dL_dimg) {
+  if (dL_dimg) {  // (first: the render backward waits for this one, nobody on the stream for the three scalars)
     ProfScope ps(K_LOSS_BWD, s);
     hipLaunchKernelGGL(k_loss_backward, grid, dim3(256), 0, s, C, H, W, img, gt, win, mapA, mapB, mapC, inv_n, lambda,
                        dL_dimg);
+  }
+  {
+    ProfScope ps(K_LOSS_FINALIZE, s);
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(1024), 0, s, partials, nblocks, inv_n, lambda, loss_out3);
   }
   return hipGetLastError();
 }
