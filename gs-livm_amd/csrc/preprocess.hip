@@ -227,13 +227,13 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   // The depth sort's four digit histograms are counted here, where the keys are made (LDS atomics, one flush of
   // the non-empty bins per workgroup): the sort needs no histogram pass of its own.  ghist_acc is library-owned
   // and zero on entry; ghist_clear is the buffer the NEXT forward will count into.
-  // (not in the STAGED variant: 50 KB of SH rows + 4 KB would drop it from 3 to 2 workgroups per CU; the sort then
-  // counts its digits itself)
+  // (the STAGED variant too: 5 KB beside its SH rows -- 12 to 50 KB -- and the record images; a near/far frame's
+  // near limit and partial depth sort hang on these counts)
   // (row 4: the tile counts summed by the keys' TOP byte -- with row 3 it tells k_scan_offsets how far into the depth
   // order the near phase of a near/far frame can reach)
-  __shared__ uint32_t dhist[STAGED ? 1 : 5][STAGED ? 1 : 256];
+  __shared__ uint32_t dhist[5][256];
   __shared__ float4 s_rec[PRE_BLOCK / 64][64 * SPLAT_F4];  // per wave: the records of its 64 Gaussians on their way out
-  if (!STAGED && ghist_acc) {
+  if (ghist_acc) {
 #pragma unroll
     for (int k = 0; k < 5; k++) dhist[k][threadIdx.x] = 0u;
     if (blockIdx.x == 0)
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the image is rewritten by the wave's next block)
     __builtin_amdgcn_wave_barrier();
   }
-  if constexpr (!STAGED) if (ghist_acc) {
+  if (ghist_acc) {
     // Gaussians without instances all carry the key 0xFFFFFFFF: counted per wave, not per lane (one address)
     const bool has = !dup, none = has && dkey == 0xFFFFFFFFu;
     const uint64_t nm = __ballot(none);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   const uint32_t ws = wave_sum_u32(tiles_wg);
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = ws;
   __syncthreads();
-  if (!STAGED && ghist_acc) {
+  if (ghist_acc) {
 #pragma unroll
     for (int k = 0; k < 5; k++) {
       const uint32_t c = dhist[k][threadIdx.x];
@@ -1632,8 +1632,11 @@ bool preprocess_counts_depth_digits(const FrameParams& fp, const float* shs, con
   // From 128 k Gaussians (with one workgroup per CU up to 1 M, so that a workgroup walks several blocks between its ~770
   // flush atomics: 640x512 / 300 k: k_preprocess +2.5 us, k_sort_hist_all's 8.6 us launch gone; 500 k: +4.8 / -9.6).
   static const long min_p = getenv("GSR_PRE_HIST_MIN_P") ? atol(getenv("GSR_PRE_HIST_MIN_P")) : (1 << 17);
-  if (fp.P <= min_p) return false;
-  return !((shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0);
+  // (with SH rows staged through LDS the kernel keeps three workgroups per CU -- it has no prefetch to cover a lone
+  // workgroup's loads --, so the digits are counted there only where a workgroup still walks several blocks: > 1 M)
+  static const bool min_p_given = getenv("GSR_PRE_HIST_MIN_P") != nullptr;
+  const bool staged = shs && !colors_precomp && sh_stage_bytes(fp.M) != 0;
+  return fp.P > (staged && !min_p_given ? (1L << 20) : min_p);
 }
 
 hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const float* scales, const float* rotations,
