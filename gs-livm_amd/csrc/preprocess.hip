@@ -200,7 +200,13 @@ static inline size_t sh_stage_bytes(int M) {
 // branch with a load in it ends in an `s_waitcnt vmcnt(0)` at the join -- vector loads return in order, so that wait
 // also waits for the NEXT block's inputs requested at the top of the iteration, and the prefetch never overlaps the
 // arithmetic.  With the branches compiled away no load is issued between the prefetch and the next iteration.
-template <bool STAGED, bool PLAIN = false>
+// PIN ("plain inputs", implied by PLAIN) = scales + rotations + SH given, nothing precomputed, no debug copy of cov3D,
+// at any SH degree: the same compile-time removal of optional loads for the LDS-staged variant.  ROWK > 0 (PIN, STAGED,
+// rows of 4 ROWK floats at a 16-byte aligned base: degree 1 and 3): the SH rows take part in the software pipeline --
+// every WAVE requests the rows of its own 64 Gaussians of the NEXT block as ROWK fully coalesced 16-byte loads per lane
+// before it works on this one, and moves them into its quarter of the LDS image when it gets there (wave-private: fences
+// instead of the two workgroup barriers per block of the block-wide copy, whose loads nothing overlapped).
+template <bool STAGED, bool PLAIN = false, bool PIN = PLAIN, int ROWK = 0>
 __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     const FrameParams fp, const float* __restrict__ means3D, const float* __restrict__ scales,
     const float* __restrict__ rotations, const float* __restrict__ opacities, const float* __restrict__ shs,
@@ -255,8 +261,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     v.s0 = v.s1 = v.s2 = v.dc0 = v.dc1 = v.dc2 = 0.f;
     v.q = make_float4(0.f, 0.f, 0.f, 0.f);
     v.mx = means3D[3 * i]; v.my = means3D[3 * i + 1]; v.mz = means3D[3 * i + 2];
-    if (PLAIN || scales) { v.s0 = scales[3 * i]; v.s1 = scales[3 * i + 1]; v.s2 = scales[3 * i + 2]; }
-    if (PLAIN || !cov3D_precomp) v.q = reinterpret_cast<const float4*>(rotations)[i];
+    if (PIN || scales) { v.s0 = scales[3 * i]; v.s1 = scales[3 * i + 1]; v.s2 = scales[3 * i + 2]; }
+    if (PIN || !cov3D_precomp) v.q = reinterpret_cast<const float4*>(rotations)[i];
     v.op = opacities[i];
     if (dc_direct) {
       const float* r = shs + (size_t)i * fp.M * 3;
@@ -276,8 +282,8 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
   const int idx_raw = blk * PRE_BLOCK + threadIdx.x;
   const bool dup = idx_raw >= fp.P;
   const int idx = dup ? fp.P - 1 : idx_raw;
-  if (STAGED) {
-    const int row0 = blk * PRE_BLOCK;
+  if (STAGED && !(ROWK > 0 && (blk + 1) * PRE_BLOCK <= fp.P)) {  // (ROWK: only the last, partial block -- its duplicate
+    const int row0 = blk * PRE_BLOCK;                            // lanes read a row another wave has staged)
     if (blk != (int)blockIdx.x) __syncthreads();  // the previous block's rows have been read
     if (row0 < fp.P) rows_to_lds(sh_rows, shs + (size_t)row0 * fp.M * 3, min(PRE_BLOCK, fp.P - row0), fp.M * 3);
     __syncthreads();
@@ -291,7 +297,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     const float pvz = Vc[2] * mx + Vc[6] * my + Vc[10] * mz + Vc[14];
     bool alive = !(pvz <= 0.2f);  // near cull only (forward.cu:221-225)
     float s0 = 0, s1 = 0, s2 = 0;
-    if (alive && (PLAIN || scales)) {  // scale cull (forward.cu:19-25)
+    if (alive && (PIN || scales)) {  // scale cull (forward.cu:19-25)
       s0 = fp.scale_modifier * in.s0;
       s1 = fp.scale_modifier * in.s1;
       s2 = fp.scale_modifier * in.s2;
@@ -304,12 +310,12 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
       const float pw = 1.0f / (ph3 + 0.0000001f);
       const float ppx = ph0 * pw, ppy = ph1 * pw;
       float c6[6];
-      if (!PLAIN && cov3D_precomp) {
+      if (!PIN && cov3D_precomp) {
 #pragma unroll
         for (int k = 0; k < 6; k++) c6[k] = cov3D_precomp[6 * idx + k];
       } else {
         cov3d_from_scale_rot(s0, s1, s2, in.q, c6);
-        if (write_cov3D) {  // debug forwards only (the views): the backward recomputes it with the same arithmetic
+        if (!PIN && write_cov3D) {  // debug forwards only (the views): the backward recomputes it with the same arithmetic
 #pragma unroll
           for (int k = 0; k < 6; k++) g.cov3D[6 * (size_t)idx + k] = c6[k];
         }
@@ -331,7 +337,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
         if (area != 0) {
           float rgb[3];
           uint8_t clampbits = 0;
-          if (!PLAIN && colors_precomp) {
+          if (!PIN && colors_precomp) {
             rgb[0] = colors_precomp[3 * idx];
             rgb[1] = colors_precomp[3 * idx + 1];
             rgb[2] = colors_precomp[3 * idx + 2];
@@ -486,8 +492,38 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_preprocess(
     };
     In a = fetch(blockIdx.x * PRE_BLOCK + threadIdx.x);
     pin(a);  // (waited for here, so that the loop itself starts with nothing pending on these registers)
+    // ROWK: this wave's 64 SH rows of a block = 64 ROWK consecutive float4s; lane l holds numbers l, l + 64, ...
+    constexpr int NPRE = ROWK > 0 ? ROWK : 1;
+    float4 pre[NPRE];
+    const int lane_ = threadIdx.x & 63, wave0 = (int)(threadIdx.x & ~63u);
+    auto rows_fetch = [&](const int blk) {  // unconditional, on addresses clamped into the array (see fetch)
+      const int first = min(blk * PRE_BLOCK + wave0, fp.P - 1);
+      const int n4 = min(64, fp.P - first) * NPRE;  // >= ROWK
+      const float4* src = reinterpret_cast<const float4*>(shs + (size_t)first * (4 * NPRE));
+#pragma unroll
+      for (int k = 0; k < NPRE; k++) pre[k] = src[min(lane_ + 64 * k, n4 - 1)];
+    };
+    auto rows_commit = [&]() {  // float4 number j of the wave's image is columns 4 (j % ROWK) .. + 3 of its row j / NPRE
+      float* img = sh_rows + wave0 * sh_row_stride(4 * NPRE);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // (the previous block's rows have been read)
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int k = 0; k < NPRE; k++) {
+        const int j = lane_ + 64 * k, r = j / NPRE, c4 = j - r * NPRE;
+        float* d = img + r * sh_row_stride(4 * NPRE) + 4 * c4;
+        d[0] = pre[k].x; d[1] = pre[k].y; d[2] = pre[k].z; d[3] = pre[k].w;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // lanes read each other's pieces: see the record image below
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    };
+    if constexpr (ROWK > 0) rows_fetch(blockIdx.x);
     for (int blk = blockIdx.x; blk < nblk; blk += (int)gridDim.x) {
+      if constexpr (ROWK > 0) {
+        if ((blk + 1) * PRE_BLOCK <= fp.P) rows_commit();  // (no memory instruction behind this branch)
+      }
       const In n = fetch((blk + (int)gridDim.x) * PRE_BLOCK + threadIdx.x);
+      if constexpr (ROWK > 0) rows_fetch(blk + (int)gridDim.x);
       work(a, blk, [&] {
         a = n;
         pin(a);
@@ -1660,7 +1696,19 @@ hipError_t launch_preprocess(const FrameParams& fp, const float* means3D, const 
   const bool few_wg = ghist_acc != nullptr && fp.P <= (1 << 20) && !wg_forced;
   const int max_wg = (stage ? 3 : few_wg ? 1 : wg_per_cu) * 256, rounds = (nb + max_wg - 1) / max_wg;
   const dim3 grid(rounds ? (nb + rounds - 1) / rounds : 1);
-  if (stage)
+  // (the staged variants: SH degree 1 and 3 with plain inputs pipeline their rows per wave, see the kernel's header)
+  const bool plain_in = shs && scales && rotations && !cov3D_precomp && !colors_precomp && !write_cov3D;
+  const bool rows16 = plain_in && (reinterpret_cast<uintptr_t>(shs) & 15u) == 0;
+  static const bool env_block_rows = getenv("GSR_PRE_BLOCK_ROWS") != nullptr;  // diagnostics: the block-wide copy
+  if (stage && rows16 && fp.M == 16 && !env_block_rows)
+    hipLaunchKernelGGL((k_preprocess<true, false, true, 12>), grid, dim3(PRE_BLOCK), stage, s, fp, means3D, scales, rotations,
+                       opacities, shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, write_cov3D,
+                       done_word, publish, ticket, ghist_acc, ghist_clear);
+  else if (stage && rows16 && fp.M == 4 && !env_block_rows)
+    hipLaunchKernelGGL((k_preprocess<true, false, true, 3>), grid, dim3(PRE_BLOCK), stage, s, fp, means3D, scales, rotations,
+                       opacities, shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, write_cov3D,
+                       done_word, publish, ticket, ghist_acc, ghist_clear);
+  else if (stage)
     hipLaunchKernelGGL(k_preprocess<true>, grid, dim3(PRE_BLOCK), stage, s, fp, means3D, scales, rotations, opacities,
                        shs, cov3D_precomp, colors_precomp, view, proj, campos, g, radii_out, write_cov3D, done_word, publish, ticket,
                        ghist_acc, ghist_clear);

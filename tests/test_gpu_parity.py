@@ -624,6 +624,24 @@ def test_huge_image_32bit_tile_keys(mode, gpu_device):
     assert fr.ranges.shape[0] == 257 * 257 and int(fr.ranges.max()) == fr.R
 
 
+@pytest.mark.parametrize("D,P", [(1, 200_003), (3, 200_003), (3, 197_120), (2, 70_001), (1, 300)])
+def test_product_forward_equals_debug_forward_with_sh(D, P, gpu_device):
+    """The non-debug forward at SH degree >= 1 runs its own compile-time variants of k_preprocess (degree 1 and 3: the
+    SH rows of the next block prefetched per wave and moved into LDS without workgroup barriers; 200 003 Gaussians =
+    782 blocks on 768 workgroups, so some walk two blocks and the last block is partial; 197 120 = 770 full blocks);
+    the debug forward, which every oracle comparison of this file goes through, takes the general variant with the
+    block-wide copy.  Same arithmetic: images, radii and the instance count must be bit-identical."""
+    sc = S.make_scene(P, 320, 200, 31 + D, sh_degree=D)
+    t, dbg = hip_forward(sc, gpu_device, debug=True)
+    t2, prod = hip_forward(sc, gpu_device, debug=False)
+    assert int(dbg[0]) == int(prod[0]) > 0
+    for i in (1, 2, 3, 4):
+        assert torch.equal(dbg[i], prod[i]), i
+    t3, again = hip_forward(sc, gpu_device, debug=False)          # (speculative this time)
+    for i in (1, 2, 3, 4):
+        assert torch.equal(dbg[i], again[i]), i
+
+
 @pytest.mark.parametrize("knob", ["GSR_SORT_BALLOT_RANK", "GSR_DEPTH_HIST_PASS", "GSR_RANGES_FROM_KEYS",
                                   "GSR_SORT_TWO_LEVEL_SCAN"])
 def test_sort_fallback_paths(knob, gpu_device):
