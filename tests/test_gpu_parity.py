@@ -624,11 +624,12 @@ def test_huge_image_32bit_tile_keys(mode, gpu_device):
     assert fr.ranges.shape[0] == 257 * 257 and int(fr.ranges.max()) == fr.R
 
 
-@pytest.mark.parametrize("D,P", [(1, 200_003), (3, 200_003), (3, 197_120), (2, 70_001), (1, 300)])
+@pytest.mark.parametrize("D,P", [(1, 200_003), (3, 200_003), (3, 197_120), (2, 70_001), (1, 300), (3, 1_000_003)])
 def test_product_forward_equals_debug_forward_with_sh(D, P, gpu_device):
     """The non-debug forward at SH degree >= 1 runs its own compile-time variants of k_preprocess (degree 1 and 3: the
     SH rows of the next block prefetched per wave and moved into LDS without workgroup barriers; 200 003 Gaussians =
-    782 blocks on 768 workgroups, so some walk two blocks and the last block is partial; 197 120 = 770 full blocks);
+    782 blocks on 391 workgroups of two blocks each, the last block partial; 197 120 = 770 full blocks; 1 000 003: six
+    blocks per workgroup, digits counted in the kernel);
     the debug forward, which every oracle comparison of this file goes through, takes the general variant with the
     block-wide copy.  Same arithmetic: images, radii and the instance count must be bit-identical."""
     sc = S.make_scene(P, 320, 200, 31 + D, sh_degree=D)
