@@ -79,7 +79,12 @@ def algorithmic_bytes(P, P_vis, R, R_bwd, W, H, M, tiles):
         "k_blend_backward": W * H * 24 + R_bwd * (40 + 36),       # SURVEY.md 8(d) per-instance figures x walked entries
         "k_compact_touched": P * 1 + P_vis * 0,
         "k_gather_records": R_bwd * 48,
-        "k_gaussian_backward": P * (108 + 12 * M) + P_vis * (111 + 12 * M) + P_vis * (64 + 12 * M),
+        # what the kernel moves (every access is unconditional, culled Gaussians included): reads radii 4, touched 1,
+        # clamp flags 1, the four gathered sums 12 + 8 + 12 + 4, mean 12, scale 12, rotation 16, SH rows 12 M; writes the
+        # nine gradient arrays in full, 108 + 12 M (zeros for culled Gaussians: callers need no memset).  PMC at C3:
+        # 447 MB against 436 MB by this formula (the earlier figure also charged SURVEY's zero fill and a cov3D read)
+        "k_gaussian_backward": P * (82 + 12 * M) + P * (108 + 12 * M),
+        "k_compact_near": P * 4,                                  # (the near candidates written are a few per cent)
         # "next" row kernels: activations read/write the 14 + 3(M-1)... floats per Gaussian once each way
         "k_activate": P * 4 * (11 + 3 * M) * 2 - P * 24,          # xyz is not touched
         "k_activate_backward": P * 4 * (8 + 3 * M) * 2 + P * 4 * 8,
@@ -124,6 +129,23 @@ def parse_args():
                     help="N > 1: time only --sync-mode (default: 'scatter' is followed by an 'allreduce' run, both reported)")
     ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
                     help="gloo = rehearsal of the multi-rank control flow (collectives staged through the host)")
+    ap.add_argument("--views-per-step", type=int, default=1,
+                    help="the reference's loop shape (lioOptimization.cpp:1691-1737, 1822-1832): K forwards of DIFFERENT "
+                         "views per optimiser iteration (the C4 yaw cameras in turn, advancing from step to step), their "
+                         "losses summed, ONE backward, one Adam step.  value counts every rendered view's pixels; "
+                         "ms_per_step is the whole iteration")
+    ap.add_argument("--rotate-views", action="store_true",
+                    help="K = 1: the camera still changes on every step (default: one fixed view, BASELINE C3)")
+    ap.add_argument("--grow-every", type=int, default=0,
+                    help="every n-th step GrowableGaussians.add_new_pointcloud adds --grow-points Gaussians in place "
+                         "(gaussian.cu:241-313; P grows every few iterations in the reference's loop); 1 GPU only")
+    ap.add_argument("--grow-points", type=int, default=20000)
+    ap.add_argument("--opacity-scale", type=float, default=1.0,
+                    help="multiplies the scene's opacities (0.1: a scene whose tiles never saturate inside the near budget "
+                         "-- the one-chain floor of the forward)")
+    ap.add_argument("--per-step", action="store_true",
+                    help="after the timed region: an extra pass of the same steps, synchronised one by one, whose ms and "
+                         "speculation counters per step go into the line under 'per_step' (diagnostic, never `value`)")
     ap.add_argument("--reference-rects", action="store_true",
                     help="bin with the reference's full 3-sigma tile squares (gsr_set_reference_rects(1)) instead of the "
                          "footprint-culled default: the reference's own instance count through the whole path")
@@ -188,8 +210,16 @@ def main():
     D = args.sh_degree
     M = (D + 1) ** 2
     g = S.make_gaussians(P, seed, sh_degree=D, aspect=W / H)
+    if args.opacity_scale != 1.0:
+        g["opacities"] = (g["opacities"] * np.float32(args.opacity_scale)).astype(np.float32)
+    K = max(1, args.views_per_step)
+    rotate = K > 1 or args.rotate_views
+    if args.grow_every and (n_gpus > 1 or args.torch_optimizer or args.no_adam or args.forward_only):
+        raise SystemExit("bench.py: --grow-every needs the fused optimiser on one GPU")
     yaw = S.C4_YAWS_DEG[rank % len(S.C4_YAWS_DEG)] if n_gpus > 1 else 0.0
     cam = S.make_camera(W, H, yaw_deg=yaw)
+    # the cameras a rank cycles through when the view changes from forward to forward (--views-per-step / --rotate-views)
+    cams = [S.make_camera(W, H, yaw_deg=y) for y in S.C4_YAWS_DEG] if rotate else [cam]
     pre = dict(means3D=g["means3D"], scales=np.log(g["scales"]), rotations=g["rotations"],
                opacities=np.log(g["opacities"] / (1.0 - g["opacities"])), shs=g["shs"])
     pre = {k: torch.from_numpy(np.ascontiguousarray(v, dtype=np.float32)) for k, v in pre.items()}
@@ -199,19 +229,24 @@ def main():
                                                torch.from_numpy(cam["viewmatrix"]).to(dev),
                                                torch.from_numpy(cam["projmatrix"]).to(dev), D,
                                                torch.from_numpy(cam["campos"]).to(dev), False)
-    if args.host == "cpp":
-        T = G.torch_ops()
-        raster_cpp = T.GaussianRasterizer(T.GaussianRasterizationSettings(
-            H, W, cam["tanfovx"], cam["tanfovy"], bg, 1.0, settings.viewmatrix, settings.projmatrix, D,
-            settings.camera_center, False))
+    def make_raster(cm):
+        vm, pm, cc = (torch.from_numpy(cm[k]).to(dev) for k in ("viewmatrix", "projmatrix", "campos"))
+        if args.host == "cpp":
+            T = G.torch_ops()
+            r_cpp = T.GaussianRasterizer(T.GaussianRasterizationSettings(
+                H, W, cm["tanfovx"], cm["tanfovy"], bg, 1.0, vm, pm, D, cc, False))
+            return lambda xyz, m2d, op, shs, scales, rotations: r_cpp.forward(xyz, m2d, op, shs=shs, scales=scales,
+                                                                              rotations=rotations)
+        return G.GaussianRasterizer(G.GaussianRasterizationSettings(H, W, cm["tanfovx"], cm["tanfovy"], bg, 1.0, vm, pm,
+                                                                    D, cc, False))
 
-        def raster(xyz, m2d, op, shs, scales, rotations):
-            return raster_cpp.forward(xyz, m2d, op, shs=shs, scales=scales, rotations=rotations)
-    else:
-        raster = G.GaussianRasterizer(settings)
+    rasters = [make_raster(cm) for cm in cams]
+    raster = rasters[0]
     dcol, dacc = S.make_upstream_grads(W, H, seed + rank)
     wc, wa = torch.from_numpy(dcol).to(dev), torch.from_numpy(dacc).to(dev)
-    means2D = torch.zeros((P, 3), device=dev, requires_grad=True)  # gradient sink, as render_utils.cuh:39-40
+    # gradient sinks, one per view of an iteration, as render_utils.cuh:39-40 (re-made when the model grows)
+    sinks = {"P": P, "t": [torch.zeros((P, 3), device=dev, requires_grad=True) for _ in range(K)]}
+    means2D = sinks["t"][0]
     target = torch.rand((3, H, W), generator=torch.Generator().manual_seed(seed)).to(dev)  # --loss photometric
     window = G.reference_window_1d()
 
@@ -242,8 +277,21 @@ def main():
         barrier()
         broadcast_ms = max_over_ranks((time.perf_counter() - t0) * 1e3) if dist is not None else None
         v = params.views
-        model = G.GaussianParameters(v["means3D"], v["features_dc"], v["features_rest"], v["scales"], v["rotations"],
-                                     v["opacities"])
+        grow = args.grow_every > 0
+        if grow:
+            # the model as capacity buffers that grow in place: room for every growth of this run
+            n_grow = (args.warmup + args.steps * (3 if args.per_step else 2)) // args.grow_every + 2
+            model = G.GrowableGaussians(P + n_grow * args.grow_points, M, dev)
+            model.P = P
+            model._bind()
+            with torch.no_grad():
+                for name, key in (("_xyz", "means3D"), ("_features_dc", "features_dc"), ("_features_rest", "features_rest"),
+                                  ("_scaling", "scales"), ("_rotation", "rotations"), ("_opacity", "opacities")):
+                    getattr(model, name).copy_(v[key])
+            grow_rng = torch.Generator().manual_seed(seed + 77)
+        else:
+            model = G.GaussianParameters(v["means3D"], v["features_dc"], v["features_rest"], v["scales"],
+                                         v["rotations"], v["opacities"])
         leaves = dict(means3D=model._xyz, features_dc=model._features_dc, features_rest=model._features_rest,
                       scales=model._scaling, rotations=model._rotation, opacities=model._opacity)
         joint = n_gpus > 1 and sync_mode != "scatter"  # views optimised jointly: gradients are exchanged
@@ -256,8 +304,26 @@ def main():
         groups = [gr for gr in model.param_groups() if gr["params"][0].numel()]
         if args.torch_optimizer:
             opt = torch.optim.Adam(groups, eps=1e-15, fused=True)
+        elif grow:
+            opt = G.GrowableAdam(model, eps=1e-15)
         else:
             opt = G.FusedAdam(groups, eps=1e-15)
+        counter = {"step": 0, "grown": 0}
+
+        def grow_model():
+            """addNewPointcloud (gaussian.cu:241-313): --grow-points new Gaussians from the scene's own distribution."""
+            n = args.grow_points
+            z = 1.0 + 39.0 * torch.rand(n, generator=grow_rng)
+            t = math.tan(math.radians(30.0))
+            xyz = torch.stack([(2 * torch.rand(n, generator=grow_rng) - 1) * 1.1 * z * t,
+                               (2 * torch.rand(n, generator=grow_rng) - 1) * 1.1 * z * t * H / W, z], 1)
+            sc2 = (0.004 + 0.056 * torch.rand((n, 3), generator=grow_rng)) ** 2
+            covs = torch.diag_embed(sc2)
+            rgbs = 255.0 * torch.rand((n, 3), generator=grow_rng)
+            model.add_new_pointcloud(xyz.to(dev), covs.to(dev), rgbs.to(dev), 1.0)
+            sinks["P"] = model.P
+            sinks["t"] = [torch.zeros((model.P, 3), device=dev, requires_grad=True) for _ in range(K)]
+            counter["grown"] += n
 
         def activated():
             if args.torch_optimizer:  # the reference's getters as separate Torch ops (gaussian.cuh:40-54)
@@ -271,21 +337,33 @@ def main():
         model.fused_tail = tail
 
         def step():
+            it = counter["step"]
+            counter["step"] += 1
+            if grow and it and it % args.grow_every == 0:
+                grow_model()
             if owner_mode:
                 MV.broadcast_gaussians(params, src=0)
             xyz, op, sc, rot, shs = activated()
+            # this iteration's views: K different cameras, advancing from step to step (one fixed camera otherwise)
+            views = [rasters[(it * K + j) % len(rasters)] for j in range(K)] if rotate else [raster] * K
             if args.forward_only:
                 with torch.no_grad():
-                    raster(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
+                    for j, rv in enumerate(views):
+                        rv(xyz, sinks["t"][j], op, shs=shs, scales=sc, rotations=rot)
                 return
-            color, radii, depth, acc = raster(xyz, means2D, op, shs=shs, scales=sc, rotations=rot)
-            means2D.grad = None
+            outs = [rv(xyz, sinks["t"][j], op, shs=shs, scales=sc, rotations=rot) for j, rv in enumerate(views)]
+            for m2d in sinks["t"]:
+                m2d.grad = None
             if args.torch_optimizer and flat_grads:
                 grads.flat.zero_()
-            if args.loss == "photometric":  # lioOptimization.cpp:1705-1710 with lambda_dssim = 0.2
-                G.photometric_loss(color, target, 0.2, window).backward()
+            # K forwards, the losses summed, ONE backward (lioOptimization.cpp:1705-1710, 1822-1825)
+            if args.loss == "photometric":  # 0.8 L1 + 0.2 (1 - SSIM), lambda_dssim = 0.2
+                loss = G.photometric_loss(outs[0][0], target, 0.2, window)
+                for o in outs[1:]:
+                    loss = loss + G.photometric_loss(o[0], target, 0.2, window)
+                loss.backward()
             else:  # upstream gradients injected directly (SURVEY.md 8(d) backward seeds): dL/dcolor = wc, dL/dacc = wa
-                torch.autograd.backward([color, acc], [wc, wa])
+                torch.autograd.backward([t for o in outs for t in (o[0], o[3])], [wc, wa] * len(outs))
             if joint:
                 MV.reduce_gradients(grads, dst=0, all_ranks=not owner_mode)
             if tail:
@@ -317,22 +395,45 @@ def main():
             prof = G.profile_read()
             dom_name = max((k for k, (ms, c) in prof.items() if c), key=lambda k: prof[k][0])
             G.profile_enable(True, only=[dom_name])
+        spec0 = G.speculation_stats()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             step()
         barrier()
         elapsed = max_over_ranks(time.perf_counter() - t0)
+        spec1 = G.speculation_stats()
+        # what the history-driven fast paths did over the TIMED region: a mispredicting run cannot hide
+        speculation = {k: spec1[k] - spec0[k] for k in spec1 if k != "near_budget_scale_q8"}
+        speculation["near_budget_scale_q8"] = spec1["near_budget_scale_q8"]
+        speculation["forwards"] = args.steps * K
         prof_timed = None
         if survey:
             G.profile_enable(False)
             prof_timed = G.profile_read()
+        per_step = None
+        if args.per_step:  # diagnostic pass, synchronised step by step (never part of `value`)
+            per_step = []
+            for _ in range(args.steps):
+                a = G.speculation_stats()
+                torch.cuda.synchronize()
+                ts = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                ms = (time.perf_counter() - ts) * 1e3
+                b = G.speculation_stats()
+                per_step.append(dict(ms=round(ms, 4), overflows=b["overflows"] - a["overflows"],
+                                     far_skips=b["far_skips"] - a["far_skips"],
+                                     far_skip_misses=b["far_skip_misses"] - a["far_skip_misses"],
+                                     near_budget_scale_q8=b["near_budget_scale_q8"], P=int(model._xyz.shape[0])))
         return dict(elapsed=elapsed, prof=prof, prof_timed=prof_timed, dom_name=dom_name, activated=activated,
-                    tail=tail, broadcast_ms=broadcast_ms, collective_bytes_per_step=(
+                    tail=tail, broadcast_ms=broadcast_ms, speculation=speculation, per_step=per_step,
+                    grown=counter["grown"], P_end=int(model._xyz.shape[0]), collective_bytes_per_step=(
                         0 if not joint else params.nbytes() * (2 if owner_mode else 1)))
 
     main_run = run_mode(args.sync_mode, survey=True)
     elapsed, prof, prof_timed, dom_name = (main_run[k] for k in ("elapsed", "prof", "prof_timed", "dom_name"))
     activated, tail = main_run["activated"], main_run["tail"]
+    P0, P = P, main_run["P_end"]  # (--grow-every: the statistics below describe the model as the run left it)
 
     # ---- workload statistics from one direct forward with the current parameters ----
     with torch.no_grad():
@@ -384,6 +485,7 @@ def main():
     # on this workload with these flags (their "_meta"), otherwise the fields stay null.
     this_meta = dict(workload=args.workload, sh_degree=D, loss=args.loss, forward_only=bool(args.forward_only),
                      reference_rects=bool(args.reference_rects), n_gpus=n_gpus)
+    plain_run = K == 1 and not rotate and not args.grow_every and args.opacity_scale == 1.0
 
     def committed(fname):
         try:
@@ -392,7 +494,15 @@ def main():
         except (OSError, ValueError):
             return None
         meta = d.get("_meta") or {}
-        return d if all(meta.get(k) == val for k, val in this_meta.items()) else None
+        return d if plain_run and all(meta.get(k) == val for k, val in this_meta.items()) else None
+
+    def source_of(fname, d):
+        """Where a counter figure of this line comes from: PMC collection cannot run inside the timed bench, so these
+        are read from the committed summary of a counter pass over the same workload -- said so in the line."""
+        if not d:
+            return None
+        return "profiles/%s (%s; counter passes run with GSR_ASYNC_FAR=0: host-decided far chain)" % (
+            fname, (d.get("_meta") or {}).get("tag", "committed counter pass"))
 
     pmc = committed("pmc_traffic_latest.json")
     # device-side names behind one profiler id (the blend backward is one of two kernels, chosen by the tile count)
@@ -410,13 +520,17 @@ def main():
         ginst = ent["SQ_INSTS_VALU"] / (launch_ms * 1e-3) / 1e9
         roofline = dict(kernel=dom, bound="valu", achieved=round(ginst, 1), peak=VALU_PEAK_GINST,
                         unit="G wave-instr/s", frac=round(ginst / VALU_PEAK_GINST, 4), traffic=traffic,
+                        traffic_source=source_of("pmc_traffic_latest.json", pmc) if traffic else None,
                         avg_launch_ms=round(launch_ms, 4), wave_instructions_per_launch=ent["SQ_INSTS_VALU"],
+                        wave_instructions_source=source_of("sq_counters_latest.json", sq),
                         # the same against the rate MEASURED for plain f32 ops at 4-8 waves per SIMD
                         # (tools/microbench/valu_rate.hip: v_fma / v_mul 3.0-3.3 cycles, v_add_f32_dpp 4.4-4.7, v_exp 8.3)
                         frac_of_measured_3cycle_rate=round(ginst / (1024 * 2.4 / 3.0), 4), hbm=hbm)
     else:
         roofline = dict(kernel=dom, bound="hbm", achieved=hbm["achieved"], peak=HBM_PEAK_GBS, unit="GB/s",
-                        frac=hbm["frac"], traffic=traffic, avg_launch_ms=round(launch_ms, 4),
+                        frac=hbm["frac"], traffic=traffic,
+                        traffic_source=source_of("pmc_traffic_latest.json", pmc) if traffic else None,
+                        avg_launch_ms=round(launch_ms, 4),
                         algorithmic_bytes_per_launch=int(alg[dom]),
                         note=("VALU-issue-bound kernel (DESIGN.md section 4); no counter summary committed for this "
                               "workload, so only its HBM figure is given") if valu_bound else None)
@@ -425,24 +539,36 @@ def main():
     raster_ms = sum(k["ms_per_step"] for k in kernels.values())
 
     ms_per_step = elapsed / args.steps * 1e3
-    mpix = n_gpus * W * H * args.steps / elapsed / 1e6
+    mpix = n_gpus * K * W * H * args.steps / elapsed / 1e6  # every rendered (and differentiated) view counts
     out = {
         "metric": "rasterizer %s Mpixels/s @%dx%d, %d Gaussians (ms_per_step = ms/frame)" %
                   ("fwd" if args.forward_only else "fwd+bwd", W, H, P),
         "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: %d Gaussians, %dx%d, SH degree %d, 1 view per GPU, %s" %
-                               (args.workload, P, W, H, D,
-                                "forward only" if args.forward_only else "fwd+bwd + Adam step"),
-                   "views_per_step": n_gpus, "parallelism": "view-parallel x%d" % n_gpus,
+        "config": {"workload": "%s: %d Gaussians, %dx%d, SH degree %d, %d view%s per GPU per step, %s" %
+                               (args.workload, P0, W, H, D, K, "" if K == 1 else "s",
+                                "forward only" if args.forward_only else
+                                ("fwd+bwd + Adam step" if K == 1 else "%d forwards, one backward, one Adam step" % K)),
+                   "views_per_step": n_gpus * K, "views_per_gpu_per_step": K,
+                   "camera": "the C4 yaw cameras in turn, a different one every forward" if rotate else "one fixed view",
+                   "grow": (dict(every_steps=args.grow_every, points=args.grow_points, added=main_run["grown"],
+                                 P_at_end=P) if args.grow_every else None),
+                   "opacity_scale": args.opacity_scale,
+                   "parallelism": "view-parallel x%d" % n_gpus,
                    "sync_mode": args.sync_mode if n_gpus > 1 else None,
                    "adam_in_step": not (args.no_adam or args.forward_only),
                    "optimizer": "torch ops" if args.torch_optimizer else
                                 ("one-kernel tail: activation chain rule + Adam + next activations (HIP)" if tail else
                                  "fused activations + fused Adam (HIP)"),
                    "loss": args.loss, "host": args.host},
-        "fps": round(1e3 / ms_per_step * n_gpus, 2),
+        "fps": round(1e3 / ms_per_step * n_gpus * K, 2),
+        "ms_per_view": round(ms_per_step / K, 4),
+        # what the history-driven fast paths did over the timed region (speculative forwards: overflows = frames binned
+        # twice; far_skips / far_skip_misses = split frames whose far chain stayed closed / had to run; near budget
+        # scale in 1/256 of the configured entries per tile)
+        "speculation": main_run["speculation"],
+        "per_step": main_run["per_step"],
         "roofline": roofline,
         "whole_path": {"kernel_ms_per_step": round(raster_ms, 4), "algorithmic_GB_per_step": round(b_path / 1e9, 3),
                        "alg_GBps_over_kernel_time": round(b_path / (raster_ms * 1e-3) / 1e9, 1) if raster_ms else None},

@@ -15,7 +15,7 @@ The directory is named `gs-livm_amd`; import it as `gs_livm_amd` (alias module a
 """
 from . import multiview, synthetic  # noqa: F401
 from ._capi import (GsrError, LIB_PATH, NumRendered, last_num_rendered, lib, mailbox_slow_path_last, mark_visible,
-                    set_binning_capacity_hint, speculation_stats, set_near_far, set_near_far_hints, last_near_far, set_far_speculation, last_far_skipped, profile_enable, profile_read,  # noqa: F401
+                    set_binning_capacity_hint, speculation_stats, set_near_far, set_near_far_thread, set_reference_rects_thread, async_outcomes_pending, set_near_far_hints, last_near_far, set_far_speculation, last_far_skipped, profile_enable, profile_read,  # noqa: F401
                     rasterize_backward, rasterize_forward, reference_rects, set_reference_rects, state_views)
 from .loss import PhotometricLoss, photometric_loss, reference_window_1d  # noqa: F401
 from .model import FusedActivations, FusedAdam, GaussianParameters, GrowableAdam, GrowableGaussians  # noqa: F401
@@ -43,4 +43,4 @@ def torch_ops():
 
 
 __all__ = ["PhotometricLoss", "photometric_loss", "reference_window_1d", "FusedActivations", "FusedAdam", "GaussianParameters", "GrowableAdam", "GrowableGaussians", "ply", "GaussianRasterizationSettings", "GaussianRasterizer", "rasterize_gaussians", "Camera", "render", "get_projection_matrix", "rasterize_forward",
-           "rasterize_backward", "mark_visible", "state_views", "set_reference_rects", "reference_rects", "last_num_rendered", "set_binning_capacity_hint", "speculation_stats", "mailbox_slow_path_last", "set_near_far", "set_near_far_hints", "last_near_far", "set_far_speculation", "last_far_skipped", "NumRendered", "lib", "torch_ops", "synthetic", "multiview", "GsrError", "LIB_PATH"]
+           "rasterize_backward", "mark_visible", "state_views", "set_reference_rects", "reference_rects", "last_num_rendered", "set_binning_capacity_hint", "speculation_stats", "mailbox_slow_path_last", "set_near_far", "set_near_far_thread", "set_reference_rects_thread", "async_outcomes_pending", "set_near_far_hints", "last_near_far", "set_far_speculation", "last_far_skipped", "NumRendered", "lib", "torch_ops", "synthetic", "multiview", "GsrError", "LIB_PATH"]

@@ -63,7 +63,9 @@ EXPORTS = ("gsr_forward", "gsr_backward", "gsr_mark_visible", "gsr_geometry_byte
            "gsr_speculation_overflows", "gsr_mailbox_slow_path_last", "gsr_set_near_far", "gsr_near_far",
            "gsr_last_near_far", "gsr_set_near_far_hints", "gsr_near_far_forwards", "gsr_set_far_speculation",
            "gsr_last_far_skipped", "gsr_far_skips", "gsr_far_skip_misses", "gsr_async_far_frames",
-           "gsr_near_budget_scale", "gsr_near_budget_feedback", "gsr_near_far_pause")
+           "gsr_near_budget_scale", "gsr_near_budget_feedback", "gsr_near_far_pause", "gsr_set_near_far_thread",
+           "gsr_set_reference_rects_thread", "gsr_async_outcomes_pending", "gsr_async_outcomes_lost",
+           "gsr_frame_note_misses")
 
 
 def lib():
@@ -133,9 +135,15 @@ def lib():
     L.gsr_near_budget_feedback.argtypes = [C.c_uint, C.c_uint, C.c_uint]
     L.gsr_near_far_pause.restype = ci
     L.gsr_near_far_pause.argtypes = [ci]
-    for n in ("gsr_far_skips", "gsr_far_skip_misses", "gsr_async_far_frames"):
+    for n in ("gsr_far_skips", "gsr_far_skip_misses", "gsr_async_far_frames", "gsr_async_outcomes_lost",
+              "gsr_frame_note_misses"):
         getattr(L, n).restype = C.c_ulonglong
         getattr(L, n).argtypes = []
+    for n in ("gsr_set_near_far_thread", "gsr_set_reference_rects_thread"):
+        getattr(L, n).restype = ci
+        getattr(L, n).argtypes = [ci]
+    L.gsr_async_outcomes_pending.restype = ci
+    L.gsr_async_outcomes_pending.argtypes = []
     L.gsr_mailbox_slow_path_last.restype = ci
     L.gsr_mailbox_slow_path_last.argtypes = [C.POINTER(MailboxEvent)]
     L.gsr_mailbox_slow_path_hits.restype = C.c_ulonglong
@@ -287,6 +295,8 @@ def speculation_stats():
     return dict(speculative_forwards=int(L.gsr_speculative_forwards()), overflows=int(L.gsr_speculation_overflows()),
                 near_far_forwards=int(L.gsr_near_far_forwards()), far_skips=int(L.gsr_far_skips()),
                 far_skip_misses=int(L.gsr_far_skip_misses()), async_far_frames=int(L.gsr_async_far_frames()),
+                async_outcomes_lost=int(L.gsr_async_outcomes_lost()), frame_note_misses=int(L.gsr_frame_note_misses()),
+                near_budget_scale_q8=int(L.gsr_near_budget_scale()),
                 mailbox_slow_path_hits=int(L.gsr_mailbox_slow_path_hits()))
 
 
@@ -300,6 +310,18 @@ def set_near_far(on):
     """Near/far frames (include/gsraster.h): speculative forwards of dense scenes bin the nearest Gaussians first and
     the rest only where a tile is still unfinished.  Returns the previous setting."""
     return bool(lib().gsr_set_near_far(int(bool(on))))
+
+
+def set_near_far_thread(mode):
+    """The same switch for the CALLING THREAD's forwards only: True / False, None = follow the process-wide value.
+    Returns the thread's previous setting (None = none)."""
+    prev = int(lib().gsr_set_near_far_thread(-1 if mode is None else int(bool(mode))))
+    return None if prev < 0 else bool(prev)
+
+
+def async_outcomes_pending():
+    """Asynchronous frames of the calling thread whose far-chain outcome has not reached the host yet (never waits)."""
+    return int(lib().gsr_async_outcomes_pending())
 
 
 def set_near_far_hints(near_entries_per_tile=None, far_capacity=None):
@@ -331,6 +353,13 @@ def set_reference_rects(on):
     tiles_touched / num_rendered / point_list / ranges / n_contrib are the reference's own; False (default) = the
     footprint-culled rectangles.  Returns the previous setting."""
     return bool(lib().gsr_set_reference_rects(int(bool(on))))
+
+
+def set_reference_rects_thread(mode):
+    """Binning mode of the CALLING THREAD's forwards only: True / False, None = follow the process-wide value.  Returns
+    the thread's previous setting (None = none)."""
+    prev = int(lib().gsr_set_reference_rects_thread(-1 if mode is None else int(bool(mode))))
+    return None if prev < 0 else bool(prev)
 
 
 def reference_rects():

@@ -25,6 +25,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <unordered_map>
 #include <vector>
 
 #include "gsr_internal.hpp"
@@ -92,7 +93,7 @@ static const char* const kKernelNames[K_COUNT] = {
     "k_sort_hist", "k_sort_scan_chunks", "k_sort_scan_top", "k_sort_scatter", "k_tile_ranges", "k_blend_forward",
     "k_blend_backward", "k_compact_touched", "k_gather_records", "k_gaussian_backward", "k_mark_visible", "k_sort_hist[depth]",
     "k_sort_scan_chunks[depth]", "k_sort_scan_top[depth]", "k_sort_scatter[depth]", "k_activate",
-    "k_activate_backward", "k_adam", "k_loss_forward", "k_loss_finalize", "k_loss_backward", "k_init_gaussians", "k_pack_ply_rows", "k_model_step", "k_tile_order", "k_live_sat"};
+    "k_activate_backward", "k_adam", "k_loss_forward", "k_loss_finalize", "k_loss_backward", "k_init_gaussians", "k_pack_ply_rows", "k_model_step", "k_tile_order", "k_live_sat", "k_compact_near"};
 
 extern "C" {
 
@@ -172,6 +173,12 @@ static std::atomic<int>& reference_rects_flag() {
   return flag;
 }
 
+// Per host thread (gsr_set_reference_rects_thread / gsr_set_near_far_thread): -1 = follow the process-wide value.  The
+// reference calls the rasterizer from several threads; a thread that needs a mode of its own for one
+// call sets it here and never disturbs the forwards of the others.
+static thread_local int t_reference_rects = -1;
+static thread_local int t_near_far = -1;
+
 static FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx, float tan_fovy, float scale_mod) {
   FrameParams fp;
   fp.P = P; fp.D = D; fp.M = M; fp.W = W; fp.H = H;
@@ -182,7 +189,7 @@ static FrameParams make_params(int P, int D, int M, int W, int H, float tan_fovx
   fp.focal_y = H / (2.0f * tan_fovy);  // rasterizer_impl.cu:210-211
   fp.focal_x = W / (2.0f * tan_fovx);
   fp.scale_modifier = scale_mod;
-  fp.ref_rects = reference_rects_flag().load(std::memory_order_relaxed);
+  fp.ref_rects = t_reference_rects >= 0 ? t_reference_rects : reference_rects_flag().load(std::memory_order_relaxed);
   return fp;
 }
 
@@ -201,6 +208,7 @@ static gsr_mailbox_event g_slow_last = {0, 0, 0, 0.0, 0, 0, 0};
 // ordered on the device (ONE stream per host thread at a time, as the reference's default-stream use): the done
 // word and the histogram pair are re-used by consecutive calls.  A thread that switches streams is detected and made
 // safe (the library drains the previous stream before re-using the words) instead of corrupting the counter.
+constexpr int MAILBOX_WORDS = 32;
 struct ThreadCtx {
   unsigned long long* mailbox = nullptr;      // host pointer (page-locked, device-mapped)
   unsigned long long* mailbox_dev = nullptr;
@@ -239,8 +247,14 @@ struct ThreadCtx {
   bool near_count_pending = false;            // the last forward ran a partial depth sort: its candidate count is in the
   uint32_t near_count_ticket = 0;             // mailbox (word 4) -- when it is most of the scene, sort everything again
   bool near_list_too_long = false;
-  bool lazy_pending = false;                  // the last forward returned before its far-chain decision was known
-  uint32_t lazy_ticket = 0, lazy_near = 0;
+  // Asynchronous frames return before their far-chain decision is known.  What each left open -- quads unfinished, and
+  // if so the far chain's instance count -- arrives in a mailbox slot of the frame's own (words 16 + 2 (seq & 7), + 1),
+  // so a thread that runs several forwards ahead of the GPU still learns every outcome (lazy_resolve): up to eight
+  // frames pending, oldest first.
+  struct Pending { uint32_t ticket, near; int w_live, w_far; };
+  Pending pending[8];
+  int pending_head = 0, pending_n = 0;
+  int w_live = 3, w_far = 1;                  // this forward's mailbox words for those two counts (3 / 1 unless asynchronous)
   const uint32_t* top_hist = nullptr;         // this forward's [count | tile sum] by top key byte (k_preprocess), or null
   ~ThreadCtx();                               // (a thread that ends gives the asynchronous mechanism back)
 };
@@ -253,7 +267,7 @@ static int ctx_prepare(ThreadCtx& c, hipStream_t stream) {
     void* h = nullptr;
     void* d = nullptr;
     void* k = nullptr;
-    if (hipHostMalloc(&h, 64, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
+    if (hipHostMalloc(&h, MAILBOX_WORDS * 8, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess ||
         hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipMalloc(&k, 64 + 2 * 5120) != hipSuccess ||
         hipMemset(k, 0, 64 + 2 * 5120) != hipSuccess)
       return fail(GSR_ERR_HIP, "cannot allocate the host-mapped mailbox: %s", hipGetErrorString(hipGetLastError()));
@@ -265,13 +279,20 @@ static int ctx_prepare(ThreadCtx& c, hipStream_t stream) {
     c.hist_flip = 0;
     c.used = false;
     c.async_state = 0;  // (a previous device's stream and signal words stay allocated: switching is rare)
-    c.lazy_pending = false;
-    for (int k = 0; k < 8; k++) c.mailbox[k] = 0;  // word 0: num_rendered; near/far frames: 1 = far count, 2 = near count
+    c.pending_n = 0;
+    // word 0: num_rendered; near/far frames: 1 = far count, 2 = near count, 3 = unfinished quads, 4 = near candidates;
+    // 16 .. 31: (unfinished quads, far count) of asynchronous frame seq in slot seq & 7
+    for (int k = 0; k < MAILBOX_WORDS; k++) c.mailbox[k] = 0;
     (void)hipDeviceSynchronize();  // the counter is zero before any stream uses it
   }
   if (c.used && stream != c.last_stream) {
     // this thread's previous forward ran on another stream: its k_preprocess may still be counting into the words
-    HIP_TRY(hipStreamSynchronize(c.last_stream));
+    // (the caller may have destroyed that stream meanwhile -- work enqueued on a destroyed stream still completes, but
+    // its handle cannot be waited on: then the whole device is drained instead)
+    if (hipStreamSynchronize(c.last_stream) != hipSuccess) {
+      (void)hipGetLastError();
+      HIP_TRY(hipDeviceSynchronize());
+    }
     if (c.far_stream) HIP_TRY(hipStreamSynchronize(c.far_stream));
   }
   c.last_stream = stream;
@@ -335,28 +356,41 @@ static int wait_num_rendered(ThreadCtx& c, hipStream_t stream, uint32_t* R_out, 
 // ORDER: the backward's tile order (k_tile_order) was computed by that forward; SPLIT: it was a near/far frame (the
 // gradient gather then walks the emitted Gaussians' descriptors instead of compacting P flags).  A note exists iff the
 // MOST RECENT forward on that blob pointer left it: every forward drops its blob's note on entry.
-enum : unsigned { NOTE_ORDER = 1u, NOTE_SPLIT = 2u };
+enum : unsigned { NOTE_ORDER = 1u, NOTE_SPLIT = 2u, NOTE_PRESENT = 4u };
+// One entry per image blob with a forward outstanding -- the reference's loop keeps the blobs of several views alive
+// until one backward (lioOptimization.cpp:1691-1737), several rendering threads at once -- so the table is a map sized
+// by need, not a ring: an entry lives until the next forward on the same blob pointer replaces it.  Blobs that are
+// freed and never used again would accumulate, so beyond NOTES_MAX entries the oldest is dropped; a backward that finds
+// no entry takes the general path (it sorts its tiles itself and compacts P flags: same results) and is counted
+// (gsr_frame_note_misses) -- every forward that reaches its blend leaves an entry, so a miss means an eviction.
+constexpr size_t NOTES_MAX = 4096;
+struct FrameNote { unsigned flags; unsigned long long age; };
 static std::mutex g_note_mu;
-static struct { const char* blob; unsigned flags; } g_notes[16] = {};
-static unsigned g_note_pos = 0;
+static std::unordered_map<const char*, FrameNote> g_notes;
+static unsigned long long g_note_clock = 0;
+static std::atomic<unsigned long long> g_note_misses{0};
 static void order_forget(const char* blob) {
   std::lock_guard<std::mutex> lk(g_note_mu);
-  for (auto& e : g_notes)
-    if (e.blob == blob) { e.blob = nullptr; e.flags = 0u; }
+  g_notes.erase(blob);
 }
 static void frame_note(const char* blob, unsigned flags) {
   std::lock_guard<std::mutex> lk(g_note_mu);
-  for (auto& e : g_notes)
-    if (e.blob == blob) { e.flags |= flags; return; }
-  g_notes[g_note_pos & 15u].blob = blob;
-  g_notes[g_note_pos++ & 15u].flags = flags;
+  auto it = g_notes.find(blob);
+  if (it != g_notes.end()) { it->second.flags |= flags; return; }
+  if (g_notes.size() >= NOTES_MAX) {
+    auto oldest = g_notes.begin();
+    for (auto e = g_notes.begin(); e != g_notes.end(); ++e)
+      if (e->second.age < oldest->second.age) oldest = e;
+    g_notes.erase(oldest);
+  }
+  g_notes.emplace(blob, FrameNote{flags, ++g_note_clock});
 }
 static void order_remember(const char* blob) { frame_note(blob, NOTE_ORDER); }
 static unsigned frame_notes(const char* blob) {
   std::lock_guard<std::mutex> lk(g_note_mu);
-  for (auto& e : g_notes)
-    if (e.blob == blob) return e.flags;
-  return 0u;
+  auto it = g_notes.find(blob);
+  if (it == g_notes.end()) { ++g_note_misses; return 0u; }
+  return it->second.flags;
 }
 
 // ---- asynchronous near/far frames ------------------------------------------------------------------------------
@@ -446,7 +480,13 @@ static bool async_far_ready(ThreadCtx& c) {
       // satisfies every wait, then the streams are abandoned
       (void)hipMemset(a, 0xFF, 8);
       (void)hipMemset(b, 0xFF, 8);
+      // (destroying a stream does not wait: its resources go once its work has completed -- the two signal words stay
+      // allocated, 16 bytes, since a wait may still be looking at them) and another thread may try its luck
+      if (probe) (void)hipStreamDestroy(probe);
+      (void)hipStreamDestroy(st);
       (void)hipGetLastError();
+      const void* me = &c;
+      (void)g_async_owner.compare_exchange_strong(me, nullptr);
       return false;
     }
     (void)hipStreamDestroy(probe);
@@ -502,27 +542,45 @@ static void budget_feedback(ThreadCtx& c, uint32_t live, uint32_t R_near, uint32
 }
 
 // What an asynchronous frame left open when gsr_forward returned -- did its far chain run, and over how many
-// instances -- is read from the mailbox the next time the thread asks (never waited for).
+// instances -- is read from the frame's mailbox slot the next time the thread asks (never waited for).  Frames are
+// resolved oldest first; one whose words have not arrived stays pending (it is NOT dropped: a thread that runs ahead of
+// the GPU, the steady state this mechanism exists for, would otherwise never count a miss nor adapt its budget).
+static std::atomic<unsigned long long> g_async_outcomes_lost{0};
 static void lazy_resolve(ThreadCtx& c) {
-  if (!c.lazy_pending) return;
-  uint32_t live = 0, far = 0;
-  if (!peek_word(c, 3, c.lazy_ticket, &live)) return;
-  if (live != 0u && !peek_word(c, 1, c.lazy_ticket, &far)) return;
-  c.lazy_pending = false;
-  c.last_far = far;
-  c.last_far_skipped = live == 0u;
-  budget_feedback(c, live, c.last_near, far);
-  c.recent_far[c.recent_far_pos] = far;
-  c.recent_far_pos = (c.recent_far_pos + 1) & 3;
-  c.have_far = true;
-  if (live == 0u) {
-    ++g_far_skips;
-    c.far_idle_streak++;
-  } else {
-    ++g_far_skip_misses;
-    c.far_idle_streak = 0;
+  while (c.pending_n > 0) {
+    const ThreadCtx::Pending& p = c.pending[c.pending_head];
+    uint32_t live = 0, far = 0;
+    if (!peek_word(c, p.w_live, p.ticket, &live)) return;
+    if (live != 0u && !peek_word(c, p.w_far, p.ticket, &far)) return;
+    budget_feedback(c, live, p.near, far);
+    c.recent_far[c.recent_far_pos] = far;
+    c.recent_far_pos = (c.recent_far_pos + 1) & 3;
+    c.have_far = true;
+    if (live == 0u) {
+      ++g_far_skips;
+      c.far_idle_streak++;
+    } else {
+      ++g_far_skip_misses;
+      c.far_idle_streak = 0;
+    }
+    if (p.ticket == c.ticket) {  // the thread's most recent forward: what gsr_last_* report
+      c.last_far = far;
+      c.last_far_skipped = live == 0u;
+      c.last_R = c.last_near + c.last_far;
+    }
+    c.pending_head = (c.pending_head + 1) & 7;
+    c.pending_n--;
   }
-  c.last_R = c.last_near + c.last_far;
+}
+static void lazy_push(ThreadCtx& c, uint32_t ticket, uint32_t near) {
+  if (c.pending_n == 8) {  // nine frames in flight: the oldest one's slot is about to be reused -- its outcome is lost,
+    ++g_async_outcomes_lost;  // which is taken for a miss (the speculation has to earn its streak again)
+    c.far_idle_streak = 0;
+    c.pending_head = (c.pending_head + 1) & 7;
+    c.pending_n--;
+  }
+  c.pending[(c.pending_head + c.pending_n) & 7] = ThreadCtx::Pending{ticket, near, c.w_live, c.w_far};
+  c.pending_n++;
 }
 
 // One binning chain: scan -> emit -> tile sort -> ranges, followed by the blend.  A whole frame is one chain over the
@@ -570,8 +628,8 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
                               /*vals_are_positions=*/true, stream));
     }
     STAGE(launch_live_sat(fp, im, g.total + 9, cnt, stream));  // which tiles did the near chain leave unfinished
-    STAGE(launch_scan_offsets_far(fp, g, cnt, ch.base, im.live_sat, chunk_first, b.tsort.counts, c.mailbox_dev + 1,
-                                  c.ticket, stream));
+    STAGE(launch_scan_offsets_far(fp, g, cnt, ch.base, im.live_sat, chunk_first, b.tsort.counts,
+                                  c.mailbox_dev + c.w_far, c.ticket, stream));
   }
   else
     STAGE(launch_scan_offsets(fp, g, cnt, chunk_first, im.ranges, im.rangesB, b.tsort.counts, ch.near_budget,
@@ -602,7 +660,7 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
   }
   // (the near blend counts the quads it leaves unfinished into the host's mailbox: done word 1, mailbox word 3)
   STAGE(launch_blend_forward(fp, g, b, im, background, out_color, out_depth, out_acc, ch.phase, c.done_counter + 1,
-                             c.mailbox_dev + 3, c.ticket, ch.phase == 1 ? aw : AsyncWords(), cnt, stream));
+                             c.mailbox_dev + c.w_live, c.ticket, ch.phase == 1 ? aw : AsyncWords(), cnt, stream));
   return GSR_OK;
 }
 
@@ -671,8 +729,9 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   //     waits for the host.  If R exceeds the capacity the kernels have clamped to it (in-bounds garbage); the
   //     host then allocates an exact blob and enqueues the binning chain again -- the only cost of a misprediction.
   ThreadCtx& c = g_ctx;
-  lazy_resolve(c);  // (what the thread's previous asynchronous frame left open, if the mailbox has it by now)
-  c.lazy_pending = false;
+  lazy_resolve(c);  // (what the thread's earlier asynchronous frames left open, as far as the mailbox has it by now)
+  c.w_live = 3;
+  c.w_far = 1;
   if (c.near_count_pending) {  // (likewise the previous partial depth sort's candidate count)
     uint32_t nn = 0;
     if (peek_word(c, 4, c.near_count_ticket, &nn)) c.near_list_too_long = (unsigned long long)nn * 3ull > (unsigned long long)P;
@@ -739,7 +798,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   // forward goes 0.31 -> 0.245 ms; at 1.5 budgets, the 640x512 shape, a split saves nothing.  In quarters:)
   static const unsigned long long env_ratio_q2 =
       getenv("GSR_NEAR_FAR_MIN_RATIO_Q2") ? strtoull(getenv("GSR_NEAR_FAR_MIN_RATIO_Q2"), nullptr, 10) : 12ull;
-  const bool near_far = speculate && near_far_flag().load() && !fp.ref_rects && near_entries > 0 &&
+  const bool near_far = speculate && (t_near_far >= 0 ? t_near_far != 0 : near_far_flag().load() != 0) && !fp.ref_rects && near_entries > 0 &&
                         budget64 < 0x20000000ull && !split_paused &&
                         (c.near_entries_override >= 0 || 4ull * (unsigned long long)hint >= env_ratio_q2 * budget64);  // (hook: always)
   // Far-chain speculation (see the near/far branch below): after two split frames in a row that left no quad
@@ -841,6 +900,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
         aw.go = c.sig_go;
         aw.gate_dev = reinterpret_cast<uint32_t*>(c.done_counter + 2);
         aw.seq = ++c.async_seq;
+        c.w_live = 16 + 2 * (int)(aw.seq & 7u);  // this frame's own outcome slot (lazy_resolve)
+        c.w_far = c.w_live + 1;
       }
       int rc = enqueue_chain(fp, g, im, b, Chain{1, Count{g.total + 6, (int)capA}, budget, 0u}, c, dord, background, out_color,
                              out_depth, out_acc, debug, stream, aw);
@@ -848,10 +909,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       Chain far_chain{2, Count{g.total + 8, (int)capB}, 0xFFFFFFFFu, capA};
       uint32_t live = 0;
       c.last_far_skipped = false;
-      c.lazy_pending = false;
       if (async_far) {
         far_chain.cnt.gate = aw.gate_dev;
         far_chain.cnt.gate_open = 2u * aw.seq + 1u;
+        // (quads left unfinished: the far chain is opened from behind the near blend's kernel boundary, render.hip)
+        HIP_TRY(launch_decide_far(g.total + 13, aw, stream));
         HIP_TRY(hipStreamWaitValue32(c.far_stream, c.sig_decide, 2u * aw.seq, hipStreamWaitValueGte));
         // (not timed by the event profiler: the chain waits on its stream for the decision and then, as a rule, only
         // launches and leaves; its kernels run beside the other stream's and would be booked twice)
@@ -877,11 +939,10 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       if (async_far && (unsigned long long)R_host - R_near <= (unsigned long long)capB) {
         // the far segment holds whatever the far chain may emit: nothing left for the host to check or to wait for
         know_far = false;
-        c.lazy_pending = true;
-        c.lazy_ticket = c.ticket;
+        lazy_push(c, c.ticket, R_near);
         R_far = 0;
       } else {
-        if ((rc = wait_num_rendered(c, stream, &live, 3)) != GSR_OK) return rc;
+        if ((rc = wait_num_rendered(c, stream, &live, c.w_live)) != GSR_OK) return rc;
         if (skip_far && live == 0u) {
           ++g_far_skips;
           c.last_far_skipped = true;
@@ -896,7 +957,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
             rc = enqueue_chain(fp, g, im, b, far_chain, c, dord, background, out_color, out_depth, out_acc, debug, stream);
             if (rc != GSR_OK) return rc;
           }
-          if ((rc = wait_num_rendered(c, stream, &R_far, 1)) != GSR_OK) return rc;
+          if ((rc = wait_num_rendered(c, stream, &R_far, c.w_far)) != GSR_OK) return rc;
         }
         c.far_idle_streak = live == 0u ? c.far_idle_streak + 1 : 0;
         budget_feedback(c, live, R_near, R_far);
@@ -964,6 +1025,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   if (host_trace)
     fprintf(stderr, "[gsr] forward returns at %.1f us (process clock)\n",
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count());
+  frame_note(iblob, NOTE_PRESENT);  // (every completed forward leaves a note: a backward that finds none was evicted)
   c.recent[c.recent_pos] = R_host;  // (all instances of the frame, emitted or not: what a one-chain frame needs)
   c.recent_pos = (c.recent_pos + 1) & 3;
   c.last_R = c.last_near + c.last_far;  // the instances this forward emitted, sorted and ranged
@@ -975,7 +1037,12 @@ int gsr_last_num_rendered(void) {
   return (int)g_ctx.last_R;
 }
 int gsr_set_near_far(int on) { return near_far_flag().exchange(on != 0 ? 1 : 0); }
-int gsr_near_far(void) { return near_far_flag().load(); }
+int gsr_set_near_far_thread(int mode) {
+  const int prev = t_near_far;
+  t_near_far = mode < 0 ? -1 : (mode ? 1 : 0);
+  return prev;
+}
+int gsr_near_far(void) { return t_near_far >= 0 ? t_near_far : near_far_flag().load(); }
 int gsr_last_near_far(unsigned* near_instances, unsigned* far_instances) {
   lazy_resolve(g_ctx);
   if (near_instances) *near_instances = g_ctx.last_near;
@@ -1030,7 +1097,18 @@ int gsr_mailbox_slow_path_last(gsr_mailbox_event* out) {
 }
 
 int gsr_set_reference_rects(int on) { return reference_rects_flag().exchange(on != 0 ? 1 : 0); }
-int gsr_reference_rects(void) { return reference_rects_flag().load(); }
+int gsr_reference_rects(void) { return t_reference_rects >= 0 ? t_reference_rects : reference_rects_flag().load(); }
+int gsr_set_reference_rects_thread(int mode) {
+  const int prev = t_reference_rects;
+  t_reference_rects = mode < 0 ? -1 : (mode ? 1 : 0);
+  return prev;
+}
+unsigned long long gsr_frame_note_misses(void) { return g_note_misses.load(); }
+unsigned long long gsr_async_outcomes_lost(void) { return g_async_outcomes_lost.load(); }
+int gsr_async_outcomes_pending(void) {
+  lazy_resolve(g_ctx);
+  return g_ctx.pending_n;
+}
 
 unsigned long long gsr_mailbox_slow_path_hits(void) { return g_mailbox_slow_hits.load(); }
 

@@ -359,6 +359,8 @@ hipError_t launch_blend_forward(const FrameParams& fp, GeomState g, BinningState
                                 AsyncWords aw, Count gate, hipStream_t s);
 hipError_t launch_live_sat(const FrameParams& fp, ImageState im, uint32_t* total_live, Count gate, hipStream_t s);
 hipError_t launch_release_go(Count gate, uint32_t* go, uint32_t seq, hipStream_t s);
+// (behind an asynchronous frame's near blend, same stream: opens the far chain if *live_quads != 0)
+hipError_t launch_decide_far(const uint32_t* live_quads, AsyncWords aw, hipStream_t s);
 hipError_t launch_tile_order(const FrameParams& fp, ImageState im, hipStream_t s);
 hipError_t launch_blend_backward(const FrameParams& fp, GeomState g, BinningState b, ImageState im, const float* bg,
                                  const float* dL_dpix, const float* dL_dacc, bool have_tile_order, hipStream_t s);
@@ -405,7 +407,7 @@ enum KernelId {
   K_PREPROCESS = 0, K_POINT_OFFSETS, K_SCAN_OFFSETS, K_EMIT, K_SORT_HIST,
   K_SORT_SCAN_CHUNKS, K_SORT_SCAN_TOP, K_SORT_SCATTER, K_TILE_RANGES, K_BLEND_FWD, K_BLEND_BWD, K_COMPACT_TOUCHED,
   K_GATHER_RECORDS, K_GAUSSIAN_BWD, K_MARK_VISIBLE, K_DSORT_HIST, K_DSORT_SCAN_CHUNKS, K_DSORT_SCAN_TOP,
-  K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_LOSS_FWD, K_LOSS_FINALIZE, K_LOSS_BWD, K_INIT_GAUSSIANS, K_PACK_PLY, K_MODEL_STEP, K_TILE_ORDER, K_LIVE_SAT, K_COUNT
+  K_DSORT_SCATTER, K_ACTIVATE, K_ACTIVATE_BWD, K_ADAM, K_LOSS_FWD, K_LOSS_FINALIZE, K_LOSS_BWD, K_INIT_GAUSSIANS, K_PACK_PLY, K_MODEL_STEP, K_TILE_ORDER, K_LIVE_SAT, K_COMPACT_NEAR, K_COUNT
 };
 void prof_begin(int id, hipStream_t s);
 void prof_end(hipStream_t s);

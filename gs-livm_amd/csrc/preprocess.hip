@@ -1745,7 +1745,7 @@ hipError_t launch_scan_offsets(const FrameParams& fp, GeomState g, Count R, uint
 hipError_t launch_compact_near(const FrameParams& fp, GeomState g, const uint32_t* top_hist, uint32_t near_budget,
                                uint32_t* keys_out, uint32_t* vals_out, uint32_t* n_out, uint32_t* ghist_near,
                                unsigned long long* publish, uint32_t ticket, hipStream_t s) {
-  ProfScope ps(K_DSORT_HIST, s);  // (booked with the depth sort: it takes the place of the digit histogram pass)
+  ProfScope ps(K_COMPACT_NEAR, s);
   hipLaunchKernelGGL(k_compact_near, dim3((fp.P + COMPACT_TILE - 1) / COMPACT_TILE), dim3(PRE_BLOCK), 0, s, fp.P, g.dkeysA,
                      top_hist, near_budget, keys_out, vals_out, n_out, ghist_near, g.dsort.scanC_status(),
                      g.dsort.tickets() + 6, publish, ticket);

@@ -346,10 +346,16 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
           if (publish)
             __hip_atomic_store(publish, ((unsigned long long)ticket << 32) | live, __ATOMIC_RELAXED,
                                __HIP_MEMORY_SCOPE_SYSTEM);
-          if (aw.decide) {  // asynchronous frame: open the far chain waiting on the other stream, or release this one
-            const uint32_t d = 2u * aw.seq + (live ? 1u : 0u);
+          // Asynchronous frame.  Nothing left to do (live == 0): the gates stay closed, so the far chain's kernels touch
+          // nothing, and the caller's stream -- ordered behind this kernel anyway -- is released from here.  Quads left
+          // unfinished: NOT decided here.  Other waves of this launch may still be parking their state, and the XCDs'
+          // L2s are not coherent: a far chain released by a word stored from inside this kernel could read quad_done
+          // or parked pixels that have not reached memory.  k_decide_far, enqueued behind this kernel on the same
+          // stream, opens the far chain after the kernel boundary has written everything back.
+          if (aw.decide && live == 0u) {
+            const uint32_t d = 2u * aw.seq;
             __hip_atomic_store(aw.gate_dev, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (live == 0u) __hip_atomic_store(aw.go, aw.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(aw.go, aw.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             __hip_atomic_store(aw.decide, d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // (after the gate word)
           }
         }
@@ -863,6 +869,22 @@ __global__ __launch_bounds__(1024) void k_live_sat(const uint8_t* __restrict__ q
   if (IN_LDS)
     for (int i = tid; i < sw * (gy + 1); i += 1024) sat[i] = S[i];
   if (tid == 0) *total_live = S[gy * sw + gx];
+}
+
+// Asynchronous near/far frame whose near blend left quads unfinished: opens the far chain that waits on the library's
+// second stream.  A launch of its own behind the near blend on the caller's stream, so that the kernel boundary -- not a
+// fence inside a kernel whose other waves are still storing -- orders the near chain's results (quad_done, the parked
+// pixel state, quad_last) before everything the far chain reads.  One thread; a frame with nothing left open was
+// decided by the near blend itself and this kernel does nothing.
+__global__ void k_decide_far(const uint32_t* __restrict__ live_quads, const AsyncWords aw) {
+  if (threadIdx.x != 0 || *live_quads == 0u) return;
+  const uint32_t d = 2u * aw.seq + 1u;
+  __hip_atomic_store(aw.gate_dev, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(aw.decide, d, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);  // (after the gate word)
+}
+hipError_t launch_decide_far(const uint32_t* live_quads, AsyncWords aw, hipStream_t s) {
+  hipLaunchKernelGGL(k_decide_far, dim3(1), dim3(64), 0, s, live_quads, aw);
+  return hipGetLastError();
 }
 
 __global__ void k_release_go(const Count gate, uint32_t* __restrict__ go, const uint32_t seq) {

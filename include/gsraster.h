@@ -90,7 +90,7 @@ unsigned long long gsr_speculation_overflows(void);
 /* Near/far frames.  A tile's list is depth-ordered and a pixel stops reading it once its transmittance
  * is below 1e-4 (forward.cu:380-383); in dense scenes every tile is finished after a few per cent of
  * its list, and emitting, sorting and ranging the rest is most of the forward.  A speculative forward in
- * the default binning mode whose predicted instance count is at least four times the near budget
+ * the default binning mode whose predicted instance count is at least three times the near budget
  * (GSR_NEAR_ENTRIES list entries per tile, default 320) therefore bins the Gaussians in two chains
  * in depth order: the NEAR Gaussians (until they fill the budget) are binned and blended; then only
  * the FAR Gaussians whose tile rectangle still contains an unfinished tile are binned (whole
@@ -99,13 +99,17 @@ unsigned long long gsr_speculation_overflows(void);
  * bit-identical to the one-chain frame; only the lists (num_rendered, point_list, ranges -- each tile's
  * list is its near segment followed by its far segment, gsr_image_view.ranges / .ranges_far) are
  * shorter.  Frames with gsr_set_reference_rects(1), debug frames and synchronous forwards are never
- * split.  gsr_set_near_far(0) / GSR_NEAR_FAR=0 switches the feature off; returns the previous value.
+ * split.  gsr_set_near_far(0) / GSR_NEAR_FAR=0 switches the feature off process-wide; returns the previous value.
+ * gsr_set_near_far_thread(mode): the same for the CALLING THREAD's forwards only (1 on, 0 off, negative = follow the
+ * process-wide value, the default) -- the reference renders from several threads, and a thread that needs a mode of its
+ * own must not disturb the others; returns the thread's previous setting (-1 = none).
  * gsr_last_near_far: 1 if the calling thread's last forward was split, with its two instance counts.
  * gsr_set_near_far_hints (test / tuning hook, calling thread): near list entries per tile (< 0 =
  * default) and the far capacity of the NEXT split forward (< 0 = from history; too small forces the
  * redo path). */
 int gsr_set_near_far(int on);
-int gsr_near_far(void);
+int gsr_set_near_far_thread(int mode);
+int gsr_near_far(void);  /* what the calling thread's next forward will use */
 int gsr_last_near_far(unsigned* near_instances, unsigned* far_instances);
 void gsr_set_near_far_hints(long long near_entries_per_tile, long long far_capacity);
 unsigned long long gsr_near_far_forwards(void);
@@ -134,6 +138,16 @@ int gsr_last_far_skipped(void);
 unsigned long long gsr_far_skips(void);       /* process-wide counters */
 unsigned long long gsr_far_skip_misses(void);
 unsigned long long gsr_async_far_frames(void);
+/* Asynchronous frames report their outcome (quads left unfinished, far-chain instances) through a mailbox slot of
+ * their own; up to eight such frames of a thread may be outstanding.  gsr_async_outcomes_pending: how many of the calling
+ * thread's are still unresolved (never waits); gsr_async_outcomes_lost: frames whose slot had to be reused before it
+ * was read (a ninth frame in flight) -- each is counted as a miss by the speculation rule.  Process-wide counter. */
+int gsr_async_outcomes_pending(void);
+unsigned long long gsr_async_outcomes_lost(void);
+/* What gsr_backward knows about the forward that filled an image blob (tile order already computed, frame was split)
+ * is kept per blob address for as long as the blob may be differentiated; a backward that finds nothing (more than
+ * 4096 blobs alive) takes the general path -- same results, one or two launches more -- and is counted here. */
+unsigned long long gsr_frame_note_misses(void);
 /* Adaptive near budget (calling thread).  The budget of a split frame is GSR_NEAR_ENTRIES (320) list entries per tile
  * times scale / 256.  A frame whose far chain ran, over less than four times the near chain's instances, raises the
  * scale by 64 (a quarter of the configured budget), up to 768; sixty-four frames in a row without a far chain lower it
@@ -230,10 +244,14 @@ int gsr_image_view_of(char* image_buffer, int width, int height, gsr_image_view*
  *      tiles_touched, num_rendered, the per-tile lists, ranges and n_contrib describe the shorter lists.
  *   1: "reference" -- getRect's square as it is: tiles_touched, num_rendered, point_list, ranges and
  *      n_contrib equal the reference's bit for bit (about 1.4x the instances at 2 M Gaussians, 1080p).
- * Process-wide, read at every gsr_forward (a backward follows the mode its forward ran in: the rectangles
+ * Process-wide default, read at every gsr_forward (a backward follows the mode its forward ran in: the rectangles
  * are stored in the blobs); the initial value comes from the environment variable GSR_REFERENCE_RECTS
- * (unset / "0" = culled).  gsr_set_reference_rects returns the previous value. */
+ * (unset / "0" = culled).  gsr_set_reference_rects returns the previous value.
+ * gsr_set_reference_rects_thread(mode): the mode of the CALLING THREAD's forwards only (1 / 0; negative = follow the
+ * process-wide value, the default); returns the thread's previous setting (-1 = none).  gsr_reference_rects: what the
+ * calling thread's next forward will use. */
 int gsr_set_reference_rects(int on);
+int gsr_set_reference_rects_thread(int mode);
 int gsr_reference_rects(void);
 
 /* getHigherMsb (rasterizer_impl.cu:35-48): number of tile-id bits the sort covers. */

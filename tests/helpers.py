@@ -18,18 +18,19 @@ def hip_forward(scene, dev, debug=True, ref_rects=False, near_far=False):
     """ref_rects: binning mode of this forward (include/gsraster.h, gsr_set_reference_rects): True = the
     reference's own tile rectangles, False = the product's default culled ones.  near_far: allow the forward to bin
     the frame in a near and a far chain (gsr_set_near_far; the product's default -- off here because most tests
-    compare the WHOLE per-tile lists with the oracle's).  The previous modes are restored."""
+    compare the WHOLE per-tile lists with the oracle's).  Both are set for the CALLING THREAD only
+    (gsr_set_*_thread): other rendering threads are not disturbed.  The thread's previous settings are restored."""
     t = to_dev(scene, dev)
-    prev = G.set_reference_rects(ref_rects)
-    prev_nf = G.set_near_far(near_far)
+    prev = G.set_reference_rects_thread(ref_rects)
+    prev_nf = G.set_near_far_thread(near_far)
     try:
         out = G.rasterize_forward(t["bg"], t["means3D"], t["colors_precomp"], t["opacities"], t["scales"],
                                   t["rotations"], scene.get("scale_modifier", 1.0), t["cov3D_precomp"],
                                   t["viewmatrix"], t["projmatrix"], scene["tanfovx"], scene["tanfovy"], scene["H"],
                                   scene["W"], t["shs"], scene["sh_degree"], t["campos"], False, debug)
     finally:
-        G.set_reference_rects(prev)
-        G.set_near_far(prev_nf)
+        G.set_reference_rects_thread(prev)
+        G.set_near_far_thread(prev_nf)
     return t, out
 
 

@@ -29,7 +29,10 @@ def ref_loss(img, gt, w1d, lam):
 
 
 @pytest.mark.parametrize("shape,lam", [((3, 45, 67), 0.2), ((3, 300, 200), 0.2), ((1, 16, 16), 0.5), ((3, 9, 7), 0.0),
-                                       ((3, 128, 130), 1.0)])
+                                       ((3, 128, 130), 1.0),
+                                       # the shapes the bench and the product run (54 x 32-pixel work units:
+                                       # 1920 = 35.6 units wide, 1080 = 33.75 high; 640 x 512 = 11.9 x 16)
+                                       ((3, 1080, 1920), 0.2), ((3, 512, 640), 0.2)])
 def test_fused_loss_matches_torch(shape, lam, gpu_device):
     gen = torch.Generator().manual_seed(shape[1])
     img = torch.rand(shape, generator=gen).to(gpu_device).requires_grad_(True)

@@ -423,11 +423,8 @@ def test_two_host_threads_render_concurrently(gpu_device):
     errors, skipped = [], []
     t_in = to_dev(sc, dev)
 
-    def forward():  # (not hip_forward: it flips the PROCESS-WIDE binning switches around the call)
-        return G.rasterize_forward(t_in["bg"], t_in["means3D"], t_in["colors_precomp"], t_in["opacities"], t_in["scales"],
-                                   t_in["rotations"], 1.0, t_in["cov3D_precomp"], t_in["viewmatrix"], t_in["projmatrix"],
-                                   sc["tanfovx"], sc["tanfovy"], sc["H"], sc["W"], t_in["shs"], sc["sh_degree"],
-                                   t_in["campos"], False, False)
+    def forward():  # hip_forward sets the binning mode and near/far for the CALLING THREAD only (gsr_set_*_thread)
+        return hip_forward(sc, dev, debug=False, near_far=True)[1]
 
     def worker(k):
         try:
@@ -452,7 +449,8 @@ def test_two_host_threads_render_concurrently(gpu_device):
             errors.append((k, repr(e)))
 
     threads = [threading.Thread(target=worker, args=(k,)) for k in range(2)]
-    prev_nf, prev_rr = G.set_near_far(True), G.set_reference_rects(False)
+    # the PROCESS-WIDE switches say the opposite of what the workers need: per-thread settings must win
+    prev_nf, prev_rr = G.set_near_far(False), G.set_reference_rects(True)
     try:
         for th in threads:
             th.start()
@@ -486,6 +484,96 @@ def test_c2_near_far(gpu_device):
     sc = S.make_scene(P, W, H, seed)
     st = _check_near_far_against_one_chain(sc, gpu_device, None)
     assert st["live_tiles"] == 0 and st["far"] == 0 and st["near"] < st["one"] // 2
+
+
+def _stack_scene(P=30_000, W=320, H=208, seed=23):
+    """Dense where it matters: a stack of 64 opaque splats in front of the camera at yaw 0 finishes every tile they
+    cover inside a small near budget; seen from other yaws the stack leaves part of the image, whose tiles stay live."""
+    g = S.make_gaussians(P, seed, sh_degree=0, aspect=W / H)
+    g["means3D"][:64, :2] = 0.0
+    g["means3D"][:64, 2] = np.linspace(0.5, 0.9, 64, dtype=np.float32)
+    g["scales"][:64] = 0.29
+    g["opacities"][:64] = 0.98
+    return g
+
+
+@pytest.mark.parametrize("n_views", [3, 20])
+def test_several_split_forwards_outstanding_then_their_backwards(n_views, gpu_device):
+    """The reference's loop (lioOptimization.cpp:1691-1737, 1822-1832): several DIFFERENT views are rendered forward,
+    their losses summed, ONE backward.  Here every forward is a split (near/far) frame with far-chain speculation forced
+    -- asynchronous where the device has stream-side waits -- and nothing waits between them: n_views frames are
+    outstanding, hits (the far chain stays closed) and misses (it runs on the second stream) interleaved, before the
+    first backward is enqueued.  Images and every gradient of every view are bit-identical to that view's synchronous
+    one-chain frame, which is checked against the oracle.  Twenty views: more frames in flight than the eight outcome
+    slots of the mailbox and than the sixteen notes the library used to keep per process -- no backward may lose its
+    forward's note (gsr_frame_note_misses), and every outcome is either counted or reported lost."""
+    dev = gpu_device
+    W, H = 320, 208
+    g = _stack_scene(W=W, H=H)
+    yaws = np.linspace(-21.0, 21.0, n_views)
+    dcol, dacc = S.make_upstream_grads(W, H, 5)
+    scenes, ref_img, ref_grad = [], [], []
+    G.set_binning_capacity_hint(0)
+    O.set_threads(min(O.max_threads(), 8))
+    for i, yaw in enumerate(yaws):
+        sc = dict(g, **S.make_camera(W, H, yaw_deg=float(yaw)), bg=np.ones(3, np.float32), scale_modifier=1.0,
+                  colors_precomp=None, cov3D_precomp=None)
+        t, one = hip_forward(sc, dev, debug=False)              # one chain (near/far off for this thread)
+        assert not G.last_near_far()[0]
+        g1 = hip_backward(sc, t, one, dcol, dacc, dev, debug=False)
+        if i % 7 == 0:                                           # ... itself within tolerance of the oracle
+            fr = O.forward(sc, tight=True)
+            check_forward(sc, fr, one, dev, debug=False)
+            dc, da = masked_grads(W, H, 5, fr.fragile)
+            want = O.backward(fr, sc, dc, da)
+            got = hip_backward(sc, t, one, dc, da, dev, debug=False)
+            for k in GRAD_NAMES:
+                grad_close(got[k], want[k], k)
+        scenes.append(sc)
+        ref_img.append([x.clone() for x in one[1:5]])
+        ref_grad.append(g1)
+    before = G.speculation_stats()
+    frames = []
+    try:
+        for sc in scenes:                                        # n_views forwards, nothing waits in between
+            G.set_near_far_hints(24, None)
+            G.set_far_speculation(True)
+            frames.append(hip_forward(sc, dev, debug=False, near_far=True))
+            assert G.last_near_far()[0]
+        for sc, (t, fwd), img, g1 in zip(scenes, frames, ref_img, ref_grad):
+            g2 = hip_backward(sc, t, fwd, dcol, dacc, dev, debug=False)
+            for i, (x, y) in enumerate(zip(img, fwd[1:5])):
+                assert torch.equal(x, y), i
+            for k in g1:
+                assert np.array_equal(g1[k], g2[k]), k
+        torch.cuda.synchronize()
+        assert G.async_outcomes_pending() == 0                   # everything has arrived by now
+    finally:
+        G.set_near_far_hints(None, None)
+        G.set_far_speculation(None)
+    st = G.speculation_stats()
+    d = {k: st[k] - before[k] for k in before if k != "near_budget_scale_q8"}
+    assert d["near_far_forwards"] == n_views and d["overflows"] == 0 and d["frame_note_misses"] == 0, d
+    # every frame's outcome was counted as a hit or a miss, or reported lost (a ninth asynchronous frame in flight)
+    assert d["far_skips"] + d["far_skip_misses"] + d["async_outcomes_lost"] == n_views, d
+    assert d["far_skips"] > 0 and (d["far_skip_misses"] > 0 or d["async_outcomes_lost"] > 0), d
+    if os.environ.get("GSR_ASYNC_FAR", "1") != "0":
+        assert d["async_far_frames"] == n_views, d
+
+
+def test_asynchronous_miss_frame_at_1080p_without_partial_sort(gpu_device):
+    """An asynchronous frame whose near chain leaves most tiles unfinished, at 1920x1080 and with fewer than 128 k
+    Gaussians -- no partial depth sort, so the first kernel of the far chain on the second stream (k_live_sat) reads what
+    the near blend's 32 640 waves stored (quad_done, parked pixel state) the moment it is released.  The release comes
+    from behind the near blend's kernel boundary (k_decide_far): bit-identical to the one-chain frame."""
+    sc = S.make_scene(100_000, 1920, 1080, 41, sh_degree=0)
+    try:
+        for _ in range(3):
+            st = _check_near_far_against_one_chain(sc, gpu_device, 12, speculate_far=True)
+            assert st["live_tiles"] > st["tiles"] // 2 and st["far"] > 0 and not st["far_skipped"]
+    finally:
+        G.set_near_far_hints(None, None)
+        G.set_far_speculation(None)
 
 
 def test_empty_input_is_a_noop(gpu_device):
@@ -641,6 +729,29 @@ def test_product_forward_equals_debug_forward_with_sh(D, P, gpu_device):
     t3, again = hip_forward(sc, gpu_device, debug=False)          # (speculative this time)
     for i in (1, 2, 3, 4):
         assert torch.equal(dbg[i], again[i]), i
+
+
+@pytest.mark.parametrize("mode", MODES)
+@pytest.mark.parametrize("D", [1, 3])
+def test_product_sh_variants_against_the_oracle(D, mode, gpu_device):
+    """The compile-time k_preprocess variants of the product's inputs at SH degree 1 and 3 (rows of the next block
+    prefetched per wave, no workgroup barriers) DIRECTLY against the oracle, not through the library's own debug
+    forward: a non-debug forward of 200 003 Gaussians (782 blocks, the last one partial), every stage of check_forward
+    -- radii, means2D, depths, conics, colours from SH, clamp flags, keys, lists, ranges, n_contrib, images -- and all
+    nine gradient groups (the backward reads the SH rows and the clamp flags the variant wrote)."""
+    P, W, H = 200_003, 320, 200
+    sc = S.make_scene(P, W, H, 31 + D, sh_degree=D)
+    O.set_threads(min(O.max_threads(), 16))
+    fr = oracle_forward(sc, mode)
+    G.set_binning_capacity_hint(0)
+    for k in range(2):                                             # synchronous, then speculative
+        t, fwd = hip_forward(sc, gpu_device, debug=False, ref_rects=(mode == "reference"))
+        check_forward(sc, fr, fwd, gpu_device, debug=False)
+    dcol, dacc = masked_grads(W, H, 31 + D, fr.fragile)
+    ref = O.backward(fr, sc, dcol, dacc)
+    got = hip_backward(sc, t, fwd, dcol, dacc, gpu_device, debug=False)
+    for k in GRAD_NAMES:
+        grad_close(got[k], ref[k], k, outlier_frac=2e-6)
 
 
 @pytest.mark.parametrize("knob", ["GSR_SORT_BALLOT_RANK", "GSR_DEPTH_HIST_PASS", "GSR_RANGES_FROM_KEYS",

@@ -26,11 +26,11 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch
     > /dev/null 2> "$out/pmc_fetch.err"
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline \
     > /dev/null 2> "$out/pmc_write.err"
-python3 tools/pmc_summary.py "$out/pmc_fetch" "$out/pmc_write" "$out/${tag}_pmc_traffic.json" workload=C3 sh_degree=0
+python3 tools/pmc_summary.py "$out/pmc_fetch" "$out/pmc_write" "$out/${tag}_pmc_traffic.json" workload=C3 sh_degree=0 tag=$tag
 echo "[profile_round] traffic done"
 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES \
     --output-format csv -d "$out/pmc_sq" -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> "$out/pmc_sq.err"
-python3 tools/sq_summary.py "$out/pmc_sq" "$out/${tag}_sq_counters.json" workload=C3 sh_degree=0
+python3 tools/sq_summary.py "$out/pmc_sq" "$out/${tag}_sq_counters.json" workload=C3 sh_degree=0 tag=$tag
 echo "[profile_round] sq done"
 rm -rf "$out/stats" "$out/pmc_fetch" "$out/pmc_write" "$out/pmc_sq"
 ls -la "$out"
