@@ -209,6 +209,37 @@ static gsr_mailbox_event g_slow_last = {0, 0, 0, 0.0, 0, 0, 0};
 // word and the histogram pair are re-used by consecutive calls.  A thread that switches streams is detected and made
 // safe (the library drains the previous stream before re-using the words) instead of corrupting the counter.
 constexpr int MAILBOX_WORDS = 32;
+
+// What a thread predicts from: kept PER VIEW.  The reference's loop renders several keyframes in turn before one
+// backward (lioOptimization.cpp:1691-1737), each Camera holding its own world_view_transform tensor for its lifetime
+// (camera.cu:36-48): the frame a forward resembles is the previous frame of the SAME camera, not the previous frame of
+// the thread.  A view is recognised by the device address of its view matrix and the image size (a guess like every
+// other prediction here: a wrong one costs a redo or a far chain, never a result).  A view seen for the first time
+// starts from the thread's most recently used history, so a caller that passes a fresh matrix tensor every frame -- or
+// renders one camera only -- gets exactly the per-thread behaviour.
+struct ViewHist {
+  const void* key = nullptr;
+  int W = 0, H = 0;
+  unsigned long long used = 0;                // LRU stamp (0 = free)
+  unsigned generation = 0;                    // bumped when the slot is given to another view
+  // speculative binning size: capacity the next forward allocates before it knows its instance count (0 = none)
+  uint32_t recent[4] = {0, 0, 0, 0};
+  int recent_pos = 0;
+  uint32_t recent_far[4] = {0, 0, 0, 0};      // far-phase instance counts of this view's recent near/far frames
+  int recent_far_pos = 0;
+  bool have_far = false;
+  int far_idle_streak = 0;                    // consecutive near/far frames of this view that left no tile live
+  // adaptive near budget (budget_feedback): the configured entries per tile x near_scale_q8 / 256
+  uint32_t near_scale_q8 = 256;
+  int near_hit_run = 0, near_miss_run = 0;
+  int split_pause = 0;                        // frames for which this view is binned in one chain again (budget_feedback)
+  bool probing = false;                       // the last miss raised the budget: the next outcome says whether it helped
+  uint32_t probe_scale_q8 = 256, probe_live = 0;
+  int raise_cooldown = 0;                     // misses do not raise the budget while this runs (it did not help)
+  bool near_list_too_long = false;            // the last partial depth sort's candidates were most of the scene
+};
+constexpr int VIEW_SLOTS = 32;
+
 struct ThreadCtx {
   unsigned long long* mailbox = nullptr;      // host pointer (page-locked, device-mapped)
   unsigned long long* mailbox_dev = nullptr;
@@ -218,23 +249,15 @@ struct ThreadCtx {
   uint32_t hist_flip = 0;
   hipStream_t last_stream = nullptr;
   bool used = false;
-  // speculative binning size: capacity the next forward allocates before it knows its instance count (0 = none)
-  uint32_t recent[4] = {0, 0, 0, 0};
-  int recent_pos = 0;
+  ViewHist views[VIEW_SLOTS];                 // per-view histories (view_hist), least recently used replaced
+  int cur = 0;                                // the view of the thread's current / last forward
+  unsigned long long view_clock = 0;
   long long hint_override = -1;               // gsr_set_binning_capacity_hint
   uint32_t last_R = 0;
-  uint32_t recent_far[4] = {0, 0, 0, 0};      // far-phase instance counts of this thread's recent near/far frames
-  int recent_far_pos = 0;
-  bool have_far = false;
   long long far_hint_override = -1;           // gsr_set_near_far_hints
   long long near_entries_override = -1;
   uint32_t last_near = 0, last_far = 0;
   bool last_was_near_far = false;
-  int far_idle_streak = 0;                    // consecutive near/far frames of this thread that left no tile live
-  // adaptive near budget (budget_feedback): the configured entries per tile x near_scale_q8 / 256
-  uint32_t near_scale_q8 = 256;
-  int near_hit_run = 0, near_miss_run = 0;
-  int split_pause = 0;                        // frames for which this thread bins in one chain again (budget_feedback)
   int far_skip_override = -1;                 // gsr_set_far_speculation: -1 auto, 0 never, 1 the next split forward
   bool last_far_skipped = false;
   // asynchronous near/far frames: a second stream for the far chain, three signal words (0 decide, 1 go), a sequence
@@ -246,12 +269,13 @@ struct ThreadCtx {
   int async_state = 0;                        // 0 not probed, 1 usable, -1 unavailable
   bool near_count_pending = false;            // the last forward ran a partial depth sort: its candidate count is in the
   uint32_t near_count_ticket = 0;             // mailbox (word 4) -- when it is most of the scene, sort everything again
-  bool near_list_too_long = false;
+  int near_count_view = 0;                    // (for that view)
+  unsigned near_count_gen = 0;
   // Asynchronous frames return before their far-chain decision is known.  What each left open -- quads unfinished, and
   // if so the far chain's instance count -- arrives in a mailbox slot of the frame's own (words 16 + 2 (seq & 7), + 1),
   // so a thread that runs several forwards ahead of the GPU still learns every outcome (lazy_resolve): up to eight
   // frames pending, oldest first.
-  struct Pending { uint32_t ticket, near; int w_live, w_far; };
+  struct Pending { uint32_t ticket, near, total; int w_live, w_far, view; unsigned gen; };
   Pending pending[8];
   int pending_head = 0, pending_n = 0;
   int w_live = 3, w_far = 1;                  // this forward's mailbox words for those two counts (3 / 1 unless asynchronous)
@@ -510,35 +534,80 @@ static bool peek_word(const ThreadCtx& c, int word, uint32_t ticket, uint32_t* o
 
 static std::atomic<unsigned long long> g_far_skips{0}, g_far_skip_misses{0}, g_async_frames{0};
 
-// Adaptive near budget.  A frame whose near chain leaves quads unfinished pays for a far chain -- the eleven launches, a
-// full depth sort, its instances -- and does not qualify for the far-chain speculation; a budget that is larger than
-// necessary only costs the near chain's extra instances (2 M Gaussians / 1080p: 480 instead of 320 entries per tile
-// +2.6 % of a step; a far chain over 5.7 M instances +38 %).  So every miss whose far chain stays below four times the
-// near chain's instances (beyond that the scene is sparse: no budget finishes its tiles) raises the thread's budget by a
-// quarter of the configured one, up to three times it, and a long run of frames without a far chain (64) takes a
+// Adaptive near budget (per view).  A frame whose near chain leaves quads unfinished pays for a far chain -- its
+// launches, the depth order of the far Gaussians, its instances -- and does not qualify for the far-chain speculation; a
+// budget that is larger than necessary only costs the near chain's extra instances (2 M Gaussians / 1080p: 480 instead
+// of 320 entries per tile +2.6 % of a step).  So a miss raises the view's budget by a quarter of the configured one, up
+// to three times it -- ON PROBATION: the next frame of the view tells whether the raise helped.  If fewer than a quarter
+// of the unfinished quads went away, those tiles do not finish for lack of budget -- sky, the border of the map, a sparse
+// corner: nothing behind the near Gaussians covers them densely -- and a bigger near chain only costs (a rotating
+// camera over the C3 scene: 7.8 M near instances at the cap instead of 2.6 M, +25 % per view); the raise is taken
+// back and no other is tried for 256 frames of that view.  A long run of frames without a far chain (64) takes a
 // sixteenth back, down to the configured budget.  (The same scene after a few dozen optimiser steps, or under the
-// photometric loss, needs 360-480 entries per tile: 1.15 -> 0.91 and 1.04 -> 1.00 ms/step.)  Not while a test hook sets
-// the budget.
-static void budget_feedback(ThreadCtx& c, uint32_t live, uint32_t R_near, uint32_t R_far) {
+// photometric loss, needs 360-480 entries per tile: 1.15 -> 0.91 and 1.04 -> 1.00 ms/step.)  Eight misses in a row of
+// frames that splitting does not shorten by a quarter (near + far instances against all the frame's, or a far chain of
+// four times the near chain) pause the splitting of that view for 256 frames.  Not while a test hook sets the budget.
+static void budget_feedback(const ThreadCtx& c, ViewHist& h, uint32_t live, uint32_t R_near, uint32_t R_far,
+                            uint32_t R_total = 0u) {
   if (c.near_entries_override >= 0) return;
+  if (h.raise_cooldown > 0) h.raise_cooldown--;
   if (live == 0u) {
-    c.near_miss_run = 0;
-    if (++c.near_hit_run >= 64 && c.near_scale_q8 > 256u) {
-      c.near_scale_q8 -= 16u;
-      c.near_hit_run = 0;
+    h.near_miss_run = 0;
+    h.probing = false;  // (a raise on probation has finished every quad: kept)
+    if (++h.near_hit_run >= 64 && h.near_scale_q8 > 256u) {
+      h.near_scale_q8 -= 16u;
+      h.near_hit_run = 0;
     }
-  } else {
-    c.near_hit_run = 0;
-    const bool sparse = (unsigned long long)R_far >= 4ull * (unsigned long long)R_near;
-    if (!sparse) c.near_scale_q8 = c.near_scale_q8 + 64u < 768u ? c.near_scale_q8 + 64u : 768u;
-    // Eight misses in a row that no budget mends (the scale is at its cap, or the scene is sparse): splitting costs
-    // more than it saves -- both chains, a full depth sort, two blends (measured on a scene that had drifted that far:
-    // +5 % over the one-chain frame) -- so the thread bins in one chain for the next 256 frames and then tries again.
-    if (++c.near_miss_run >= 8 && (sparse || c.near_scale_q8 >= 768u)) {
-      c.split_pause = 256;
-      c.near_miss_run = 0;
+    return;
+  }
+  h.near_hit_run = 0;
+  const bool sparse = (unsigned long long)R_far >= 4ull * (unsigned long long)R_near;
+  const bool useless = sparse || (R_total != 0u && ((unsigned long long)R_near + R_far) * 4ull >= 3ull * R_total);
+  bool reverted = false;
+  if (h.probing) {  // the previous miss raised the budget: did that finish at least a quarter of the quads it left?
+    h.probing = false;
+    if ((unsigned long long)live * 4ull > (unsigned long long)h.probe_live * 3ull) {
+      h.near_scale_q8 = h.probe_scale_q8;
+      h.raise_cooldown = 256;
+      reverted = true;
     }
   }
+  if (!sparse && !reverted && h.raise_cooldown == 0 && h.near_scale_q8 < 768u) {
+    h.probe_scale_q8 = h.near_scale_q8;
+    h.probe_live = live;
+    h.probing = true;
+    h.near_scale_q8 = h.near_scale_q8 + 64u < 768u ? h.near_scale_q8 + 64u : 768u;
+  }
+  if (!useless) {
+    h.near_miss_run = 0;
+  } else if (++h.near_miss_run >= 8) {
+    h.split_pause = 256;
+    h.near_miss_run = 0;
+  }
+}
+
+// The history the calling thread keeps for a view (see ViewHist).  A new view inherits the most recently used one's.
+static ViewHist& view_hist(ThreadCtx& c, const void* key, int W, int H) {
+  int lru = 0, mru = -1;
+  for (int k = 0; k < VIEW_SLOTS; k++) {
+    ViewHist& v = c.views[k];
+    if (v.used && v.key == key && v.W == W && v.H == H) {
+      v.used = ++c.view_clock;
+      c.cur = k;
+      return v;
+    }
+    if (v.used < c.views[lru].used) lru = k;
+    if (v.used && (mru < 0 || v.used > c.views[mru].used)) mru = k;
+  }
+  ViewHist& v = c.views[lru];
+  const unsigned gen = v.generation + 1u;
+  if (mru >= 0 && mru != lru) v = c.views[mru];
+  else if (mru < 0) v = ViewHist();
+  v.key = key; v.W = W; v.H = H;
+  v.generation = gen;
+  v.used = ++c.view_clock;
+  c.cur = lru;
+  return v;
 }
 
 // What an asynchronous frame left open when gsr_forward returned -- did its far chain run, and over how many
@@ -552,16 +621,15 @@ static void lazy_resolve(ThreadCtx& c) {
     uint32_t live = 0, far = 0;
     if (!peek_word(c, p.w_live, p.ticket, &live)) return;
     if (live != 0u && !peek_word(c, p.w_far, p.ticket, &far)) return;
-    budget_feedback(c, live, p.near, far);
-    c.recent_far[c.recent_far_pos] = far;
-    c.recent_far_pos = (c.recent_far_pos + 1) & 3;
-    c.have_far = true;
-    if (live == 0u) {
-      ++g_far_skips;
-      c.far_idle_streak++;
-    } else {
-      ++g_far_skip_misses;
-      c.far_idle_streak = 0;
+    if (live == 0u) ++g_far_skips;
+    else ++g_far_skip_misses;
+    ViewHist& h = c.views[p.view];
+    if (h.generation == p.gen) {  // (unless the slot has gone to another view meanwhile)
+      budget_feedback(c, h, live, p.near, far, p.total);
+      h.recent_far[h.recent_far_pos] = far;
+      h.recent_far_pos = (h.recent_far_pos + 1) & 3;
+      h.have_far = true;
+      h.far_idle_streak = live == 0u ? h.far_idle_streak + 1 : 0;
     }
     if (p.ticket == c.ticket) {  // the thread's most recent forward: what gsr_last_* report
       c.last_far = far;
@@ -572,14 +640,16 @@ static void lazy_resolve(ThreadCtx& c) {
     c.pending_n--;
   }
 }
-static void lazy_push(ThreadCtx& c, uint32_t ticket, uint32_t near) {
+static void lazy_push(ThreadCtx& c, uint32_t ticket, uint32_t near, uint32_t total) {
   if (c.pending_n == 8) {  // nine frames in flight: the oldest one's slot is about to be reused -- its outcome is lost,
     ++g_async_outcomes_lost;  // which is taken for a miss (the speculation has to earn its streak again)
-    c.far_idle_streak = 0;
+    const ThreadCtx::Pending& p = c.pending[c.pending_head];
+    if (c.views[p.view].generation == p.gen) c.views[p.view].far_idle_streak = 0;
     c.pending_head = (c.pending_head + 1) & 7;
     c.pending_n--;
   }
-  c.pending[(c.pending_head + c.pending_n) & 7] = ThreadCtx::Pending{ticket, near, c.w_live, c.w_far};
+  c.pending[(c.pending_head + c.pending_n) & 7] =
+      ThreadCtx::Pending{ticket, near, total, c.w_live, c.w_far, c.cur, c.views[c.cur].generation};
   c.pending_n++;
 }
 
@@ -734,9 +804,12 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   c.w_far = 1;
   if (c.near_count_pending) {  // (likewise the previous partial depth sort's candidate count)
     uint32_t nn = 0;
-    if (peek_word(c, 4, c.near_count_ticket, &nn)) c.near_list_too_long = (unsigned long long)nn * 3ull > (unsigned long long)P;
+    ViewHist& hv = c.views[c.near_count_view];
+    if (peek_word(c, 4, c.near_count_ticket, &nn) && hv.generation == c.near_count_gen)
+      hv.near_list_too_long = (unsigned long long)nn * 3ull > (unsigned long long)P;
     c.near_count_pending = false;
   }
+  ViewHist& h = view_hist(c, viewmatrix, width, height);  // what this view's recent frames predict
   {
     const int rc = ctx_prepare(c, stream);
     if (rc != GSR_OK) return rc;
@@ -765,7 +838,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     hint = (uint32_t)c.hint_override;
     c.hint_override = -1;
   } else {
-    for (int k = 0; k < 4; k++) hint = c.recent[k] > hint ? c.recent[k] : hint;
+    for (int k = 0; k < 4; k++) hint = h.recent[k] > hint ? h.recent[k] : hint;
     if (hint) hint = (uint32_t)std::min<unsigned long long>(0x7fffffffull, (unsigned long long)hint * 5 / 4 + 65536);
   }
   const bool speculate = !debug && !env_sync && hint > 0;
@@ -787,11 +860,11 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   const int tiles_n = fp.gx * fp.gy;
   const long long near_entries = c.near_entries_override >= 0
                                      ? c.near_entries_override
-                                     : (env_near_entries * (long long)c.near_scale_q8 + 255) / 256;  // (budget_feedback)
+                                     : (env_near_entries * (long long)h.near_scale_q8 + 255) / 256;  // (budget_feedback)
   const unsigned long long budget64 = (unsigned long long)tiles_n * (unsigned long long)near_entries;
   bool split_paused = false;
-  if (c.split_pause > 0 && c.near_entries_override < 0) {  // (budget_feedback: this thread's splits kept missing)
-    c.split_pause--;
+  if (h.split_pause > 0 && c.near_entries_override < 0) {  // (budget_feedback: this view's splits kept missing)
+    h.split_pause--;
     split_paused = true;
   }
   // (three times: BASELINE C2 -- 500 k Gaussians at 1280x720, 3.6 M instances, 3.1 budgets -- bins 1.15 M of them and its
@@ -803,7 +876,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
                         (c.near_entries_override >= 0 || 4ull * (unsigned long long)hint >= env_ratio_q2 * budget64);  // (hook: always)
   // Far-chain speculation (see the near/far branch below): after two split frames in a row that left no quad
   // unfinished (or when the test hook asks) the thread's next split frame expects its far chain to stay idle.
-  const bool speculate_far = near_far && (c.far_skip_override >= 0 ? c.far_skip_override == 1 : c.far_idle_streak >= 2);
+  const bool speculate_far = near_far && (c.far_skip_override >= 0 ? c.far_skip_override == 1 : h.far_idle_streak >= 2);
   const bool speculation_forced = near_far && c.far_skip_override == 1;  // (test hook: also overrides the guard below)
   if (speculation_forced) c.far_skip_override = -1;
   // Depth order of the Gaussians.  Such a frame needs it for the NEAR candidates only (k_compact_near): they are
@@ -812,15 +885,17 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   static const bool env_full_sort = getenv("GSR_FULL_DEPTH_SORT") != nullptr;  // diagnostics / fallback
   // (not while the candidates are more than a third of the scene -- the line is drawn at top-byte granularity, a factor
   // of four in depth: the last partial sort's count says so; every 64th frame tries again)
-  if (c.near_list_too_long && (c.ticket & 63u) == 0u) c.near_list_too_long = false;
+  if (h.near_list_too_long && (c.ticket & 63u) == 0u) h.near_list_too_long = false;
   const bool partial_sort = speculate_far && c.top_hist != nullptr && !env_full_sort &&
-                            (!c.near_list_too_long || speculation_forced);
+                            (!h.near_list_too_long || speculation_forced);
   const uint32_t* near_order = g.order;
   if (partial_sort) {
     STAGE(launch_compact_near(fp, g, c.top_hist, (uint32_t)budget64, g.dkeysB, g.dvalsB, g.total + 15,
                               g.dsort.ghist_near((size_t)P), c.mailbox_dev + 4, c.ticket, stream));
     c.near_count_pending = true;
     c.near_count_ticket = c.ticket;
+    c.near_count_view = c.cur;
+    c.near_count_gen = h.generation;
     STAGE(launch_depth_sort(g.dkeysB, g.dvalsB, g.nkeys2, g.nvals2, g.dsort, Count{g.total + 15, P},
                             g.dsort.ghist_near((size_t)P), /*vals_are_positions=*/false, stream));
     near_order = g.dvalsB;
@@ -859,8 +934,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       if (capB_forced) {
         capB = (uint32_t)c.far_hint_override;
         c.far_hint_override = -1;
-      } else if (c.have_far) {
-        for (int k = 0; k < 4; k++) capB = c.recent_far[k] > capB ? c.recent_far[k] : capB;
+      } else if (h.have_far) {
+        for (int k = 0; k < 4; k++) capB = h.recent_far[k] > capB ? h.recent_far[k] : capB;
         capB = (uint32_t)std::min<unsigned long long>(0x7fffffffull - capA, (unsigned long long)capB * 5 / 4 + 65536);
       } else {
         capB = hint > budget ? hint - budget : 0u;  // no history: room for every instance behind the budget
@@ -939,7 +1014,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       if (async_far && (unsigned long long)R_host - R_near <= (unsigned long long)capB) {
         // the far segment holds whatever the far chain may emit: nothing left for the host to check or to wait for
         know_far = false;
-        lazy_push(c, c.ticket, R_near);
+        lazy_push(c, c.ticket, R_near, R_host);
         R_far = 0;
       } else {
         if ((rc = wait_num_rendered(c, stream, &live, c.w_live)) != GSR_OK) return rc;
@@ -959,8 +1034,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
           }
           if ((rc = wait_num_rendered(c, stream, &R_far, c.w_far)) != GSR_OK) return rc;
         }
-        c.far_idle_streak = live == 0u ? c.far_idle_streak + 1 : 0;
-        budget_feedback(c, live, R_near, R_far);
+        h.far_idle_streak = live == 0u ? h.far_idle_streak + 1 : 0;
+        budget_feedback(c, h, live, R_near, R_far, R_host);
       }
       if (host_trace)
         fprintf(stderr, "[gsr] near/far forward: capacity %u + %u, near %u, far %u of %u instances, %u unfinished quads%s, "
@@ -972,9 +1047,9 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       ++g_speculative_forwards;
       ++g_near_far_forwards;
       if (know_far) {
-        c.recent_far[c.recent_far_pos] = R_far;
-        c.recent_far_pos = (c.recent_far_pos + 1) & 3;
-        c.have_far = true;
+        h.recent_far[h.recent_far_pos] = R_far;
+        h.recent_far_pos = (h.recent_far_pos + 1) & 3;
+        h.have_far = true;
       }
       c.last_was_near_far = true;
       redo = R_far > capB;
@@ -1026,8 +1101,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     fprintf(stderr, "[gsr] forward returns at %.1f us (process clock)\n",
             std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count());
   frame_note(iblob, NOTE_PRESENT);  // (every completed forward leaves a note: a backward that finds none was evicted)
-  c.recent[c.recent_pos] = R_host;  // (all instances of the frame, emitted or not: what a one-chain frame needs)
-  c.recent_pos = (c.recent_pos + 1) & 3;
+  h.recent[h.recent_pos] = R_host;  // (all instances of the frame, emitted or not: what a one-chain frame needs)
+  h.recent_pos = (h.recent_pos + 1) & 3;
   c.last_R = c.last_near + c.last_far;  // the instances this forward emitted, sorted and ranged
   return key;
 }
@@ -1052,13 +1127,15 @@ int gsr_last_near_far(unsigned* near_instances, unsigned* far_instances) {
 void gsr_set_near_far_hints(long long near_entries_per_tile, long long far_capacity) {
   g_ctx.near_entries_override = near_entries_per_tile < 0 ? -1 : near_entries_per_tile;
   g_ctx.far_hint_override = far_capacity < 0 ? -1 : (far_capacity > 0x7fffffffll ? 0x7fffffffll : far_capacity);
-  if (far_capacity < 0) g_ctx.have_far = false;  // forget the far history as well
+  if (far_capacity < 0)  // forget the far history as well
+    for (auto& v : g_ctx.views) v.have_far = false;
 }
 unsigned long long gsr_near_far_forwards(void) { return g_near_far_forwards.load(); }
 int gsr_set_far_speculation(int mode) {
   const int prev = g_ctx.far_skip_override;
   g_ctx.far_skip_override = mode < 0 ? -1 : (mode ? 1 : 0);
-  if (mode < 0) g_ctx.far_idle_streak = 0;
+  if (mode < 0)
+    for (auto& v : g_ctx.views) v.far_idle_streak = 0;
   return prev;
 }
 int gsr_last_far_skipped(void) {
@@ -1066,17 +1143,18 @@ int gsr_last_far_skipped(void) {
   return g_ctx.last_far_skipped ? 1 : 0;
 }
 unsigned long long gsr_async_far_frames(void) { return g_async_frames.load(); }
+// (the three hooks below act on the view of the calling thread's last forward)
 unsigned gsr_near_budget_scale(void) {
   lazy_resolve(g_ctx);
-  return g_ctx.near_scale_q8;
+  return g_ctx.views[g_ctx.cur].near_scale_q8;
 }
 unsigned gsr_near_budget_feedback(unsigned unfinished_quads, unsigned near_instances, unsigned far_instances) {
-  budget_feedback(g_ctx, unfinished_quads, near_instances, far_instances);
-  return g_ctx.near_scale_q8;
+  budget_feedback(g_ctx, g_ctx.views[g_ctx.cur], unfinished_quads, near_instances, far_instances);
+  return g_ctx.views[g_ctx.cur].near_scale_q8;
 }
 int gsr_near_far_pause(int frames) {
-  const int prev = g_ctx.split_pause;
-  if (frames >= 0) g_ctx.split_pause = frames;
+  const int prev = g_ctx.views[g_ctx.cur].split_pause;
+  if (frames >= 0) g_ctx.views[g_ctx.cur].split_pause = frames;
   return prev;
 }
 unsigned long long gsr_far_skips(void) { return g_far_skips.load(); }
@@ -1084,7 +1162,8 @@ unsigned long long gsr_far_skip_misses(void) { return g_far_skip_misses.load(); 
 long long gsr_set_binning_capacity_hint(long long capacity) {
   const long long prev = g_ctx.hint_override;
   g_ctx.hint_override = capacity < 0 ? -1 : (capacity > 0x7fffffffll ? 0x7fffffffll : capacity);
-  if (capacity == 0) g_ctx.recent[0] = g_ctx.recent[1] = g_ctx.recent[2] = g_ctx.recent[3] = 0;
+  if (capacity == 0)  // (every view's: the thread's next forward is synchronous whatever it looks at)
+    for (auto& v : g_ctx.views) v.recent[0] = v.recent[1] = v.recent[2] = v.recent[3] = 0;
   return prev;
 }
 unsigned long long gsr_speculative_forwards(void) { return g_speculative_forwards.load(); }

@@ -148,18 +148,28 @@ unsigned long long gsr_async_outcomes_lost(void);
  * is kept per blob address for as long as the blob may be differentiated; a backward that finds nothing (more than
  * 4096 blobs alive) takes the general path -- same results, one or two launches more -- and is counted here. */
 unsigned long long gsr_frame_note_misses(void);
-/* Adaptive near budget (calling thread).  The budget of a split frame is GSR_NEAR_ENTRIES (320) list entries per tile
+/* Per-view histories.  Everything a speculative forward predicts from -- the binning capacity, the far capacity, the
+ * far-chain speculation's streak, the near budget below -- is kept per VIEW of the calling thread: a view is recognised
+ * by the device address of its view matrix and the image size (the reference renders several keyframes in turn before
+ * one backward, each Camera holding its matrices for its lifetime: lioOptimization.cpp:1691-1737, camera.cu:36-48).
+ * Up to 32 views per thread, least recently used replaced; a view seen for the first time starts from the thread's most
+ * recently used history, so a caller with one camera, or one that passes a fresh matrix tensor every frame, sees the
+ * per-thread behaviour.  A wrong guess costs a redo or a far chain, never a result.
+ * Adaptive near budget (per view).  The budget of a split frame is GSR_NEAR_ENTRIES (320) list entries per tile
  * times scale / 256.  A frame whose far chain ran, over less than four times the near chain's instances, raises the
- * scale by 64 (a quarter of the configured budget), up to 768; sixty-four frames in a row without a far chain lower it
- * by 16, down to 256.  gsr_near_budget_scale returns the current scale; gsr_near_budget_feedback (test hook) feeds the
- * outcome of a frame -- unfinished quads after the near chain, near and far instance counts -- to the rule as a forward
- * does and returns the scale after it.  The rule rests while gsr_set_near_far_hints sets the budget. */
+ * scale by 64 (a quarter of the configured budget), up to 768, ON PROBATION: if the view's next frame still leaves more
+ * than three quarters of those quads unfinished, the tiles do not finish for lack of budget (sky, the border of the
+ * map) -- the raise is taken back and none is tried for 256 frames of the view.  Sixty-four frames in a row without a
+ * far chain lower the scale by 16, down to 256.  gsr_near_budget_scale returns the current scale of the view of the
+ * calling thread's last forward; gsr_near_budget_feedback (test hook) feeds the outcome of a frame -- unfinished quads
+ * after the near chain, near and far instance counts -- to that view's rule as a forward does and returns the scale
+ * after it.  The rule rests while gsr_set_near_far_hints sets the budget. */
 unsigned gsr_near_budget_scale(void);
 unsigned gsr_near_budget_feedback(unsigned unfinished_quads, unsigned near_instances, unsigned far_instances);
-/* Eight such misses in a row that no budget mends (the scale is at its cap, or the far chain is at least four times
- * the near chain: a sparse scene) pause the splitting: the thread bins its next 256 frames in one chain and then tries
- * again.  gsr_near_far_pause(frames): returns the frames left of the calling thread's pause and, if frames >= 0, sets
- * them (0 ends a pause). */
+/* Eight misses in a row of frames that splitting does not shorten by a quarter (near + far instances against all the
+ * frame's; or a far chain of at least four times the near chain: a sparse scene) pause the splitting: the view's next
+ * 256 frames are binned in one chain, then it tries again.  gsr_near_far_pause(frames): returns the frames left of the
+ * pause of the view of the calling thread's last forward and, if frames >= 0, sets them (0 ends a pause). */
 int gsr_near_far_pause(int frames);
 
 /* Replaces CudaRasterizer::Rasterizer::backward (rasterizer.h:53-88,

@@ -76,47 +76,56 @@ def test_argument_errors_are_reported_not_crashed():
 
 
 def test_adaptive_near_budget_rule():
-    """include/gsraster.h, "Adaptive near budget": host-side rule, no device involved."""
+    """include/gsraster.h, "Adaptive near budget": host-side rule, no device involved.  fb(unfinished quads, near
+    instances, far instances) feeds one frame's outcome to the rule of the calling thread's current view."""
     L = G.lib()
     fb = L.gsr_near_budget_feedback
     assert L.gsr_near_budget_scale() == 256
     assert fb(10, 1000, 4000) == 256             # a miss over a HUGE remainder (a sparse scene): no budget helps
-    assert fb(10, 1000, 3999) == 320             # any other miss: + a quarter of the configured budget
-    for k in range(6):
-        s = fb(3, 1000, 10)
-    assert s == 704 and L.gsr_near_far_pause(-1) == 0
-    s = fb(3, 1000, 10)
-    assert s == 768                              # capped at three times the configured budget ...
-    assert L.gsr_near_far_pause(-1) == 256       # ... and this was the eighth miss in a row: splitting pauses
-    assert L.gsr_near_far_pause(0) == 256
+    assert fb(100, 1000, 3999) == 320            # any other miss: + a quarter of the configured budget, on probation
+    assert fb(40, 1000, 10) == 384               # it finished more than a quarter of those quads: kept, and raised again
+    assert fb(0, 1000, 0) == 384                 # a hit: the raise on probation is kept
+    # a raise that does not help is taken back, and none is tried for 256 frames of the view
+    assert fb(100, 1000, 10) == 448
+    assert fb(90, 1000, 10) == 384               # 90 of 100 quads still unfinished: sky, the border of the map ...
+    for k in range(255):
+        assert fb(90, 1000, 10) == 384
+    assert fb(90, 1000, 10) == 448               # ... then the rule tries again
+    assert fb(90, 1000, 10) == 384
+    assert L.gsr_near_far_pause(-1) == 0         # (misses of frames that splitting shortens never pause it)
+    # raises stop at three times the configured budget
+    for k in range(256):
+        fb(1 << 20, 1000, 10)
+    live = 1 << 20
+    for want in (512, 576, 640, 704, 768, 768, 768, 768):
+        live //= 2
+        assert fb(live, 1000, 10) == want
+    # sixty-four hits in a row take a sixteenth back, never below the configured budget
     for k in range(63):
-        assert fb(0, 1000, 0) == 768             # hits ...
-    assert fb(0, 1000, 0) == 752                 # ... sixty-four in a row: a sixteenth back
-    assert fb(5, 1000, 10) == 768                # a miss restarts the run (and stays within the cap)
+        assert fb(0, 1000, 0) == 768
+    assert fb(0, 1000, 0) == 752
     for k in range(64 * 40):
         s = fb(0, 1000, 0)
-    assert s == 256                              # and never below the configured budget
+    assert s == 256
     for k in range(200):
         assert fb(0, 1000, 0) == 256
-    # misses that no budget mends pause the splitting: a sparse scene at once ...
-    assert L.gsr_near_far_pause(-1) == 0
+    # eight misses in a row over a far chain of four times the near chain (a sparse scene) pause the splitting
     for k in range(7):
         fb(10, 1000, 9000)
     assert L.gsr_near_far_pause(-1) == 0
     fb(10, 1000, 9000)
     assert L.gsr_near_far_pause(-1) == 256 and L.gsr_near_budget_scale() == 256
     assert L.gsr_near_far_pause(0) == 256 and L.gsr_near_far_pause(-1) == 0
-    # ... a dense one with the eighth miss in a row, by which the budget has reached its cap
+    # ... in a row: a frame that splitting does shorten restarts the count
     for k in range(7):
-        fb(10, 1000, 500)
-    assert L.gsr_near_budget_scale() == 704 and L.gsr_near_far_pause(-1) == 0
+        fb(10, 1000, 9000)
     fb(10, 1000, 500)
-    assert L.gsr_near_budget_scale() == 768 and L.gsr_near_far_pause(-1) == 256
-    L.gsr_near_far_pause(0)
-    fb(0, 1000, 0)                               # a hit ends the run of misses
     for k in range(7):
-        fb(10, 1000, 500)
+        fb(10, 1000, 9000)
     assert L.gsr_near_far_pause(-1) == 0
-    for k in range(64 * 40):
+    fb(10, 1000, 9000)
+    assert L.gsr_near_far_pause(-1) == 256
+    L.gsr_near_far_pause(0)
+    for k in range(64 * 40):                     # (leave the thread's rule as it was found)
         fb(0, 1000, 0)
     assert L.gsr_near_budget_scale() == 256
