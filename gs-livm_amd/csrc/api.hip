@@ -588,25 +588,25 @@ static void budget_feedback(const ThreadCtx& c, ViewHist& h, uint32_t live, uint
 
 // The history the calling thread keeps for a view (see ViewHist).  A new view inherits the most recently used one's.
 static ViewHist& view_hist(ThreadCtx& c, const void* key, int W, int H) {
-  int lru = 0, mru = -1;
+  int hit = -1, lru = 0, mru = -1;
   for (int k = 0; k < VIEW_SLOTS; k++) {
-    ViewHist& v = c.views[k];
-    if (v.used && v.key == key && v.W == W && v.H == H) {
-      v.used = ++c.view_clock;
-      c.cur = k;
-      return v;
-    }
-    if (v.used < c.views[lru].used) lru = k;
+    const ViewHist& v = c.views[k];
+    if (v.used && v.key == key && v.W == W && v.H == H) { hit = k; continue; }
+    if (v.used < c.views[lru].used || lru == hit) lru = k;
     if (v.used && (mru < 0 || v.used > c.views[mru].used)) mru = k;
   }
-  ViewHist& v = c.views[lru];
-  const unsigned gen = v.generation + 1u;
-  if (mru >= 0 && mru != lru) v = c.views[mru];
-  else if (mru < 0) v = ViewHist();
-  v.key = key; v.W = W; v.H = H;
-  v.generation = gen;
+  const bool known = hit >= 0 && (c.views[hit].recent[0] | c.views[hit].recent[1] | c.views[hit].recent[2] |
+                                  c.views[hit].recent[3]) != 0u;
+  const int slot = hit >= 0 ? hit : lru;
+  ViewHist& v = c.views[slot];
+  if (!known) {  // a new view, or one whose history was forgotten: the thread's most recent history
+    const unsigned gen = hit >= 0 ? v.generation : v.generation + 1u;
+    v = mru >= 0 ? c.views[mru] : ViewHist();
+    v.key = key; v.W = W; v.H = H;
+    v.generation = gen;
+  }
   v.used = ++c.view_clock;
-  c.cur = lru;
+  c.cur = slot;
   return v;
 }
 

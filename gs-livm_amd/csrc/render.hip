@@ -431,11 +431,16 @@ __global__ __launch_bounds__(256) void k_blend_backward(
   const float dp0 = inside ? dL_dpix[pid] : 0.f, dp1 = inside ? dL_dpix[N + pid] : 0.f,
               dp2 = inside ? dL_dpix[2 * N + pid] : 0.f;
   const float dacc = inside ? dL_dacc[pid] : 0.f;  // the reference reads this unguarded (backward.cu:497)
-  const float bg_dot = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
-  const float neg_Tf_bg = -T_final * bg_dot;  // per-pixel constant of the background term (backward.cu:578-581)
   float T = T_final;
-  float ar0 = 0.f, ar1 = 0.f, ar2 = 0.f;  // accum_rec
-  float nacc = 1.0f;                      // 1 - accum_acc_rec: the form dL_dalpha uses; its update is one multiply
+  // ONE recurrence instead of the reference's four (accum_rec[3], accum_acc_rec; backward.cu:533-571).  dL/dalpha of a
+  // splat is T (q - S) with q = colour . dL/dpixel + 1 * dL/dacc of THIS splat and S = the same dot product of what lies
+  // behind it (accum_rec . dL/dpixel + accum_acc_rec * dL/dacc); folding the splat in, accum <- accum + alpha (c - accum)
+  // for every channel, is S <- S + alpha (q - S): the difference dL/dalpha has just used.  The background is the last
+  // thing behind every splat, so S starts at bg . dL/dpixel and the reference's separate term
+  // (-T_final / (1 - alpha)) bg . dL/dpixel (backward.cu:578-581) is carried by the recurrence: T_i (1 - alpha_{i+1}) ..
+  // (1 - alpha_last) = T_final / (1 - alpha_i).  Five instructions per (pixel, splat) instead of twelve, one state
+  // register instead of five.
+  float S = bg[0] * dp0 + bg[1] * dp1 + bg[2] * dp2;
 
   // this lane's pair slot (first 8 floats) and row slot (last 4) inside an entry's 12 floats
   // (row r of the wave owns floats [3r, 3r + 2]: its pair of wave totals and its share of the ninth value -- one
@@ -508,13 +513,11 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         const float oma = 1.0f - alpha;
         const float rom = __builtin_amdgcn_rcpf(oma);
         const float Tn = T * rom;  // T / (1 - alpha)
-        const float d0 = b.z - ar0, d1 = b.w - ar1, d2 = blue - ar2, da = nacc;
+        const float D = __builtin_fmaf(b.z, dp0, __builtin_fmaf(b.w, dp1, __builtin_fmaf(blue, dp2, dacc))) - S;
         if (__ballot(ok) != 0ull) {
           const float G = ok ? Graw : 0.0f;
           const float dch = alpha * Tn;
-          float dL_dalpha = d0 * dp0 + d1 * dp1 + d2 * dp2 + da * dacc;
-          dL_dalpha *= Tn;
-          dL_dalpha += rom * neg_Tf_bg;
+          const float dL_dalpha = Tn * D;
           // Factors common to every pixel of the splat (opacity, -0.5, 0.5*W, 0.5*H) are applied once per
           // instance when the four quads are combined, not per pixel.
           const float dLG = G * dL_dalpha;  // dL/dG up to the opacity factor; also the opacity partial itself
@@ -544,10 +547,7 @@ __global__ __launch_bounds__(256) void k_blend_backward(
         // accum + alpha (c - accum) == alpha c + (1 - alpha) accum: the differences are the ones dL_dalpha used and
         // each update is one in-place fma.
         T = Tn;
-        ar0 = __builtin_fmaf(alpha, d0, ar0);
-        ar1 = __builtin_fmaf(alpha, d1, ar1);
-        ar2 = __builtin_fmaf(alpha, d2, ar2);
-        nacc = nacc * oma;  // 1 - (acc + alpha (1 - acc)) = (1 - acc)(1 - alpha)
+        S = __builtin_fmaf(alpha, D, S);
       }
     }
     __syncthreads();
@@ -645,8 +645,15 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
   for (int t = tid + 8192; t < T; t += 1024) order[atomicAdd(&bins[walk(t)], 1u)] = (uint32_t)t;
 }
 
+// experiment knobs (A/B builds: GSR_EXTRA_RENDER_FLAGS=-DGSR_BWD_...=..)
+#ifndef GSR_BWD_STRIP_BRANCH
+#define GSR_BWD_STRIP_BRANCH 1
+#endif
+#ifndef GSR_BWD_MIN_WAVES
+#define GSR_BWD_MIN_WAVES 1
+#endif
 template <int TW>  // tiles (= waves) per workgroup; the waves never synchronise
-__global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
+__global__ __launch_bounds__(64 * TW, GSR_BWD_MIN_WAVES) void k_blend_backward_tile(
     const FrameParams fp, const uint2* __restrict__ ranges, const uint32_t* __restrict__ quad_last_in,
     const uint32_t* __restrict__ point_list, const float4* __restrict__ splats, const uint2* __restrict__ slotinfo,
     const float* __restrict__ bg, const float* __restrict__ final_T, const uint32_t* __restrict__ n_contrib,
@@ -674,7 +681,7 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
   const float bg0 = bg[0], bg1 = bg[1], bg2 = bg[2];
 
   // per-pixel state, k = 0..3 (fully unrolled: registers)
-  float pfy[4], T[4], ar0[4], ar1[4], ar2[4], nacc[4], dp0[4], dp1[4], dp2[4], dacc[4], nTfbg[4];
+  float pfy[4], T[4], S[4], dp0[4], dp1[4], dp2[4], dacc[4];
   int lastc[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) {
@@ -688,9 +695,8 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
     dp1[k] = inside ? dL_dpix[N + pid] : 0.f;
     dp2[k] = inside ? dL_dpix[2 * N + pid] : 0.f;
     dacc[k] = inside ? dL_dacc[pid] : 0.f;  // the reference reads this unguarded (backward.cu:497)
-    nTfbg[k] = -T[k] * (bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k]);  // background term (backward.cu:578-581)
-    ar0[k] = ar1[k] = ar2[k] = 0.f;  // accum_rec
-    nacc[k] = 1.0f;                  // 1 - accum_acc_rec
+    // the one recurrence of k_blend_backward (see there): what lies behind the last contributor is the background
+    S[k] = bg0 * dp0[k] + bg1 * dp1[k] + bg2 * dp2[k];
   }
 
   // staging of list entry `k` counted from the back of [0, n): record, gradient slot, tile-level hit test
@@ -753,13 +759,12 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
         const float oma = 1.0f - alpha;
         const float rom = __builtin_amdgcn_rcpf(oma);
         const float Tn = T[k] * rom;  // T / (1 - alpha)
-        const float d0 = eb.z - ar0[k], d1 = eb.w - ar1[k], d2 = blue - ar2[k];
-        if (__ballot(ok) != 0ull) {  // some pixel of this 16 x 4 strip takes the splat
+        const float D =
+            __builtin_fmaf(eb.z, dp0[k], __builtin_fmaf(eb.w, dp1[k], __builtin_fmaf(blue, dp2[k], dacc[k]))) - S[k];
+        if (!GSR_BWD_STRIP_BRANCH || __ballot(ok) != 0ull) {  // some pixel of this 16 x 4 strip takes the splat
           const float G = ok ? Graw : 0.0f;
           const float dch = alpha * Tn;
-          float dL_dalpha = d0 * dp0[k] + d1 * dp1[k] + d2 * dp2[k] + nacc[k] * dacc[k];
-          dL_dalpha *= Tn;
-          dL_dalpha += rom * nTfbg[k];
+          const float dL_dalpha = Tn * D;
           const float dLG = G * dL_dalpha;  // dL/dG up to the opacity factor; also the opacity partial itself
           const float sy = dLG * dy;
           c0 = __builtin_fmaf(dch, dp0[k], c0);
@@ -773,10 +778,7 @@ __global__ __launch_bounds__(64 * TW) void k_blend_backward_tile(
         // Fold this splat into the "everything behind the next one" accumulators (the reference does it at the top of
         // its next iteration from saved (last_alpha, last_color), backward.cu:533-543): accum + alpha (c - accum)
         T[k] = Tn;
-        ar0[k] = __builtin_fmaf(alpha, d0, ar0[k]);
-        ar1[k] = __builtin_fmaf(alpha, d1, ar1[k]);
-        ar2[k] = __builtin_fmaf(alpha, d2, ar2[k]);
-        nacc[k] = nacc[k] * oma;  // 1 - (acc + alpha (1 - acc)) = (1 - acc)(1 - alpha)
+        S[k] = __builtin_fmaf(alpha, D, S[k]);
       }
       if (__ballot(abits != 0u) != 0ull) {
         // the lane's pixels share dx: sum dLG dx = dx sum dLG, sum dLG dx^2 = dx^2 sum dLG, sum dLG dx dy = dx sum dLG dy
