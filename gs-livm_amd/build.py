@@ -78,8 +78,11 @@ def build_torch_binding(force=False, verbose=False):
     from torch.utils import cpp_extension as ce
 
     out = os.path.join(HERE, "_gsraster_torch.so")
-    src = os.path.join(CSRC, "torch_binding.cpp")
-    if not (force or _stale(out, [src] + HEADERS + [LIB, os.path.abspath(__file__)])):
+    # torch_binding.cpp: the rasterizer's operator surface (+ the pybind11 module); torch_next.cpp: the hosts of the rows
+    # either side of it (fused loss, activations + Adam, growth, PLY export), declared in gsr_torch_next.hpp
+    srcs = [os.path.join(CSRC, "torch_binding.cpp"), os.path.join(CSRC, "torch_next.cpp")]
+    hdrs = [os.path.join(CSRC, "gsr_torch_next.hpp"), os.path.join(CSRC, "gsr_torch_surface.hpp")]
+    if not (force or _stale(out, srcs + hdrs + HEADERS + [LIB, os.path.abspath(__file__)])):
         return out
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     inc = []
@@ -89,7 +92,7 @@ def build_torch_binding(force=False, verbose=False):
     cmd = (["g++", "-O2", "-fPIC", "-shared", "-std=c++17", "-Wall", "-Wno-unused-variable", "-Wno-sign-compare", "-Wno-attributes",
             "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1", "-DTORCH_EXTENSION_NAME=_gsraster_torch",
             "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)] + inc +
-           [src, "-o", out, "-L" + tlib, "-L" + HERE, "-lgsraster_hip", "-lc10", "-lc10_hip", "-ltorch_cpu",
+           srcs + ["-o", out, "-L" + tlib, "-L" + HERE, "-lgsraster_hip", "-lc10", "-lc10_hip", "-ltorch_cpu",
             "-ltorch_hip", "-ltorch", "-ltorch_python", "-Wl,-rpath," + tlib, "-Wl,-rpath,$ORIGIN",
             "-Wl,-rpath,/opt/rocm/lib"])
     o = _run(cmd)

@@ -214,7 +214,19 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
     if (threadIdx.x == 0) s_done = 0u;
     __syncthreads();  // the only barrier: at the start, where no wave waits for a slower one
   }
-  const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  // (wave-uniform by construction; made scalars by hand, see k_blend_backward_tile)
+#ifndef GSR_FWD_SCALAR
+#define GSR_FWD_SCALAR 0  // (scalarising the range / wave index by hand measured +3 %: more SALU on the walk's critical path)
+#endif
+#ifndef GSR_FWD_ONECMP
+#define GSR_FWD_ONECMP 1
+#endif
+#if GSR_FWD_SCALAR
+#define GSR_FWD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#else
+#define GSR_FWD_UNIFORM(x) (x)
+#endif
+  const int lane = threadIdx.x & 63, wq = GSR_FWD_UNIFORM(threadIdx.x >> 6);
   float4* sA = sAll[wq][0];
   float4* sB = sAll[wq][1];
   float4* sC = sAll[wq][2];
@@ -228,12 +240,13 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
   const float pfx = (float)px, pfy = (float)py;
   const float qx0 = (float)qx, qy0 = (float)qy;
   if (PHASE == 2 && quad_done[quad]) return;  // finished by the near phase
-  const uint2 range = PHASE == 2 ? rangesB[tile] : ranges[tile];
+  const uint2 range_v = PHASE == 2 ? rangesB[tile] : ranges[tile];
+  const uint2 range = make_uint2(GSR_FWD_UNIFORM(range_v.x), GSR_FWD_UNIFORM(range_v.y));
   const int n = (int)(range.y - range.x);
   uint32_t pos0 = 0;  // list position of this segment's first entry
   if (PHASE == 2) {
     const uint2 rn = ranges[tile];
-    pos0 = rn.y - rn.x;
+    pos0 = GSR_FWD_UNIFORM(rn.y - rn.x);
   }
   const size_t pid = (size_t)fp.W * py + px;
   const size_t N = (size_t)fp.W * fp.H;
@@ -286,11 +299,20 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
       const float dx = ra.x - pfx, dy = ra.y - pfy;
       const float power = splat_power(ra.z, ra.w, rb.x, dx, dy);  // = log2(e) x the reference's power
       const float alpha = fminf(0.99f, rb.y * __builtin_amdgcn_exp2f(power));
+#if GSR_FWD_ONECMP
+      const bool take = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+      const float test_T = T * (1.0f - alpha);
+      const bool low = test_T < 0.0001f;  // (one compare: `stop` and `ok` are both mask operations on it)
+      const bool stop = take && low;
+      done = done || stop;
+      const bool ok = take && !low;
+#else
       bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
       const float test_T = T * (1.0f - alpha);
       const bool stop = ok && (test_T < 0.0001f);
       done = done || stop;
       ok = ok && !stop;
+#endif
       const float wgt = ok ? alpha * T : 0.0f;
       C0 += rb.z * wgt;
       C1 += rb.w * wgt;
@@ -662,12 +684,16 @@ __global__ __launch_bounds__(64 * TW, GSR_BWD_MIN_WAVES) void k_blend_backward_t
     const uint2* __restrict__ rangesB) {
   __shared__ float4 sE[TW][64][3];  // (x, y, A', B' | C', opacity, r, g | b, -, -, -) per staged entry
   __shared__ uint32_t sSlot[TW][64], sId[TW][64];
-  const int lane = threadIdx.x & 63, wq = threadIdx.x >> 6;
+  // (wave-uniform values are made scalars by hand -- the compiler cannot know that a loaded value is the same in every
+  // lane and would keep list positions and LDS bases in vector registers, with vector instructions to update them)
+  const int lane = threadIdx.x & 63, wq = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   if (blockIdx.x * TW + wq >= fp.gx * fp.gy) return;
-  const int tile = tile_order ? (int)tile_order[blockIdx.x * TW + wq] : blockIdx.x * TW + wq;
+  const int tile = __builtin_amdgcn_readfirstlane(tile_order ? (int)tile_order[blockIdx.x * TW + wq]
+                                                             : (int)(blockIdx.x * TW + wq));
   const uint32_t ql0 = quad_last_in[4 * tile], ql1 = quad_last_in[4 * tile + 1], ql2 = quad_last_in[4 * tile + 2],
                  ql3 = quad_last_in[4 * tile + 3];
-  const int n = (int)max(max(ql0, ql1), max(ql2, ql3));  // entries [0, n) of the tile's list can carry gradient
+  // entries [0, n) of the tile's list can carry gradient
+  const int n = __builtin_amdgcn_readfirstlane((int)max(max(ql0, ql1), max(ql2, ql3)));
   if (n == 0) return;
   const int tile_x = tile % fp.gx, tile_y = tile / fp.gx;
   // the tile's list = its near segment followed by its far segment (near/far frames; (0, 0) otherwise)

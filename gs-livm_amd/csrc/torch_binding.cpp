@@ -28,6 +28,7 @@
 #include <tuple>
 
 #include "gsraster.h"
+#include "gsr_torch_next.hpp"  // the hosts of the rows either side of the rasterizer (torch_next.cpp): bound below
 
 // The declarations this file implements.  In the GS-LIVM tree they are the reference's OWN headers, untouched
 // (-DGSR_REFERENCE_HEADER='"gs/rasterizer.cuh"', which pulls in gs/rasterize_points.cuh); standalone (this repo, the
@@ -330,5 +331,43 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            py::arg("means3D"), py::arg("means2D"), py::arg("opacities"), py::arg("shs") = py::none(),
            py::arg("colors_precomp") = py::none(), py::arg("scales") = py::none(), py::arg("rotations") = py::none(),
            py::arg("cov3D_precomp") = py::none());
+
+  // ---- gsr_torch_next.hpp: the C++ hosts of the "next" rows, so that the tests can hold them against the Python route
+  namespace nx = gsr_torch;
+  auto n = m.def_submodule("next", "C++/LibTorch hosts of the fused loss, activations + Adam, growth and PLY export");
+  n.def("reference_window_1d", &nx::reference_window_1d, py::arg("window_size") = 11, py::arg("sigma") = 1.5f);
+  n.def("photometric_loss",
+        [opt](torch::Tensor image, torch::Tensor gt, float lambda_dssim, py::object window) {
+          return nx::photometric_loss(image, gt, lambda_dssim, opt(window));
+        },
+        py::arg("image"), py::arg("gt"), py::arg("lambda_dssim") = 0.2f, py::arg("window1d") = py::none());
+  n.def("photometric_loss_parts",
+        [opt](torch::Tensor image, torch::Tensor gt, float lambda_dssim, py::object window) {
+          return nx::photometric_loss_parts(image, gt, lambda_dssim, opt(window));
+        },
+        py::arg("image"), py::arg("gt"), py::arg("lambda_dssim") = 0.2f, py::arg("window1d") = py::none());
+  n.def("activate", [](torch::Tensor s, torch::Tensor r, torch::Tensor o, torch::Tensor dc, torch::Tensor rest) {
+    const nx::Activated a = nx::activate(s, r, o, dc, rest);
+    return std::make_tuple(a.scaling, a.rotation, a.opacity, a.features);
+  });
+  py::class_<nx::FusedAdam>(n, "FusedAdam")
+      .def(py::init<std::vector<torch::Tensor>, std::vector<double>, double, double, double>(), py::arg("params"),
+           py::arg("lrs"), py::arg("beta1") = 0.9, py::arg("beta2") = 0.999, py::arg("eps") = 1e-15)
+      .def("step", &nx::FusedAdam::step, py::arg("zero_grad") = true)
+      .def("step_model",
+           [](nx::FusedAdam& self, torch::Tensor gx, torch::Tensor gs, torch::Tensor gr, torch::Tensor go,
+              torch::Tensor gf) {
+             const nx::Activated a = self.step_model(gx, gs, gr, go, gf);
+             return std::make_tuple(a.scaling, a.rotation, a.opacity, a.features);
+           })
+      .def("replace_param", &nx::FusedAdam::replace_param)
+      .def("step_count", &nx::FusedAdam::step_count)
+      .def("params", &nx::FusedAdam::params)
+      .def("exp_avg", &nx::FusedAdam::exp_avg)
+      .def("exp_avg_sq", &nx::FusedAdam::exp_avg_sq);
+  n.def("init_gaussians", &nx::init_gaussians);
+  n.def("pack_ply_rows", &nx::pack_ply_rows);
+  n.def("write_ply", &nx::write_ply);
+  n.def("ply_attribute_names", &nx::ply_attribute_names);
 }
 #endif  // GSR_NO_PYBIND

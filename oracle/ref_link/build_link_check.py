@@ -17,6 +17,11 @@ OUT = os.path.join(ROOT, "oracle", "_ref")
 WANT = ["_RasterizeGaussians::forward(", "_RasterizeGaussians::backward(", "GaussianRasterizer::mark_visible(",
         "GaussianRasterizer::rasterize_gaussians(", "GaussianRasterizer::forward(", "RasterizeGaussiansCUDA(",
         "RasterizeGaussiansBackwardCUDA(", "markVisible("]
+# gsr_torch_next.hpp (torch_next.cpp): the hosts of the rows either side of the rasterizer
+WANT_NEXT = ["gsr_torch::reference_window_1d(", "gsr_torch::photometric_loss(", "gsr_torch::photometric_loss_parts(",
+             "gsr_torch::activate(", "gsr_torch::FusedAdam::FusedAdam(", "gsr_torch::FusedAdam::step(",
+             "gsr_torch::FusedAdam::step_model(", "gsr_torch::FusedAdam::replace_param(", "gsr_torch::init_gaussians(",
+             "gsr_torch::pack_ply_rows(", "gsr_torch::write_ply(", "gsr_torch::ply_attribute_names"]  # ([abi:cxx11] follows the name)
 
 
 def main():
@@ -26,7 +31,8 @@ def main():
         return 0
     pkg = os.path.join(ROOT, "gs-livm_amd")
     report = os.path.join(OUT, "link_check.txt")
-    deps = [os.path.join(pkg, "csrc", "torch_binding.cpp"), os.path.join(HERE, "caller.cpp"), os.path.abspath(__file__),
+    deps = [os.path.join(pkg, "csrc", "torch_binding.cpp"), os.path.join(pkg, "csrc", "torch_next.cpp"),
+            os.path.join(pkg, "csrc", "gsr_torch_next.hpp"), os.path.join(HERE, "caller.cpp"), os.path.abspath(__file__),
             os.path.join(ROOT, "include", "gsraster.h"), hdr]  # (not the .so: the link depends on its ABI header only)
     if os.path.exists(report) and all(os.path.getmtime(d) <= os.path.getmtime(report) for d in deps):
         print(open(report).read().strip().splitlines()[-1] + " (cached: sources unchanged)")
@@ -36,21 +42,27 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     tlib = os.path.join(os.path.dirname(torch.__file__), "lib")
     inc = ["-I" + p for p in ce.include_paths() + [sysconfig.get_paths()["include"], os.path.join(ROOT, "include"),
-                                                    "/opt/rocm/include", os.path.join(REF, "include", "gs")]]
+                                                    "/opt/rocm/include", os.path.join(REF, "include", "gs"),
+                                                    os.path.join(pkg, "csrc")]]
     common = ["g++", "-O1", "-fPIC", "-std=c++17", "-w", "-D__HIP_PLATFORM_AMD__=1", "-DUSE_ROCM=1",
               "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)] + inc
     obj = os.path.join(OUT, "torch_binding_ref.o")
     subprocess.check_call(common + ["-DGSR_NO_PYBIND", "-DGSR_REFERENCE_HEADER=\"gs/rasterizer.cuh\"", "-c",
                                     os.path.join(pkg, "csrc", "torch_binding.cpp"), "-o", obj])
+    obj_next = os.path.join(OUT, "torch_next_ref.o")
+    subprocess.check_call(common + ["-c", os.path.join(pkg, "csrc", "torch_next.cpp"), "-o", obj_next])
     exe = os.path.join(OUT, "link_check")
     pylib = sysconfig.get_config_var("LDLIBRARY").replace("lib", "", 1).rsplit(".so", 1)[0]
-    subprocess.check_call(common + [os.path.join(HERE, "caller.cpp"), obj, "-o", exe, "-L" + tlib, "-L" + pkg,
+    subprocess.check_call(common + [os.path.join(HERE, "caller.cpp"), obj, obj_next, "-o", exe, "-L" + tlib, "-L" + pkg,
                                     "-lgsraster_hip", "-lc10", "-lc10_hip", "-ltorch_cpu", "-ltorch_hip", "-ltorch",
                                     "-ltorch_python", "-l" + pylib, "-Wl,-rpath," + tlib, "-Wl,-rpath," + pkg,
                                     "-Wl,-rpath,/opt/rocm/lib", "-Wl,--no-undefined"])
     syms = subprocess.check_output(["nm", "-C", "--defined-only", obj], text=True).splitlines()
     strong = [ln.split(" ", 2)[2] for ln in syms if len(ln.split(" ", 2)) == 3 and ln.split(" ", 2)[1] == "T"]
-    missing = [w for w in WANT if not any(s.startswith(w) for s in strong)]
+    syms_next = subprocess.check_output(["nm", "-C", "--defined-only", obj_next], text=True).splitlines()
+    strong_next = [ln.split(" ", 2)[2] for ln in syms_next if len(ln.split(" ", 2)) == 3 and ln.split(" ", 2)[1] == "T"]
+    missing = [w for w in WANT if not any(s.startswith(w) for s in strong)] + \
+              [w for w in WANT_NEXT if not any(s.startswith(w) for s in strong_next)]
     if missing:
         print("not defined as strong symbols:", missing)
         return 1
@@ -62,6 +74,9 @@ def main():
         f.write("strong symbols in torch_binding_ref.o (nm -C --defined-only, type T):\n")
         for w in WANT:
             f.write("  T %s\n" % next(s for s in strong if s.startswith(w))[:160])
+        f.write("strong symbols in torch_next_ref.o:\n")
+        for w in WANT_NEXT:
+            f.write("  T %s\n" % next(s for s in strong_next if s.startswith(w))[:160])
         f.write(r.stdout)
     return 0
 

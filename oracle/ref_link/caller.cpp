@@ -5,10 +5,14 @@
 // with -DGSR_NO_PYBIND -DGSR_REFERENCE_HEADER='"gs/rasterizer.cuh"', i.e. the build INTEGRATION.md section 1
 // describes.  A successful link proves that the binding defines every member the reference headers declare, with the
 // signatures they declare; running it exercises the host-side argument rules (no device is touched).
+#include <cmath>
 #include <cstdio>
 #include <stdexcept>
 
 #include "gs/rasterizer.cuh"
+// the hosts of the rows either side of the rasterizer have no declaration in the reference (its versions are
+// header-inline Torch code or private members): a GS-LIVM translation unit includes this header next to its own
+#include "gsr_torch_next.hpp"
 
 int main() {
   GaussianRasterizationSettings st = {
@@ -52,6 +56,33 @@ int main() {
                            st.projmatrix, 0.5f, 0.375f, 48, 64, shs, 0, st.camera_center, false, false);
     failures++;
   } catch (const c10::Error&) {}
+  // gsr_torch_next.hpp: every entry point odr-used (strong definitions needed at link time) ...
+  auto n_win = &gsr_torch::reference_window_1d;
+  auto n_loss = &gsr_torch::photometric_loss;
+  auto n_parts = &gsr_torch::photometric_loss_parts;
+  auto n_act = &gsr_torch::activate;
+  auto n_step = &gsr_torch::FusedAdam::step;
+  auto n_tail = &gsr_torch::FusedAdam::step_model;
+  auto n_grow = &gsr_torch::FusedAdam::replace_param;
+  auto n_init = &gsr_torch::init_gaussians;
+  auto n_pack = &gsr_torch::pack_ply_rows;
+  auto n_ply = &gsr_torch::write_ply;
+  auto n_names = &gsr_torch::ply_attribute_names;
+  if (!n_win || !n_loss || !n_parts || !n_act || !n_step || !n_tail || !n_grow || !n_init || !n_pack || !n_ply || !n_names)
+    failures++;
+  // ... and the host-side rules that need no device: the reference's window (loss_utils.cuh:24-31: NOT symmetric), the
+  // attribute list of construct_list_of_attributes (gaussian.cu:474-492), argument checks before any launch
+  {
+    const torch::Tensor w = gsr_torch::reference_window_1d();
+    if (w.numel() != 11 || std::fabs(w.sum().item<float>() - 1.0f) > 1e-6f || w[0].item<float>() == w[10].item<float>())
+      failures++;
+    const auto names = gsr_torch::ply_attribute_names(4);
+    if (names.size() != 14 + 3 * 4 || names[6] != "f_dc_0" || names[9] != "f_rest_0" || names.back() != "rot_3") failures++;
+    try { gsr_torch::photometric_loss(torch::zeros({3, 8, 8}), torch::zeros({3, 8, 8})); failures++; }  // host tensors
+    catch (const std::invalid_argument&) {}
+    try { gsr_torch::FusedAdam opt({torch::zeros({4, 3})}, {1e-3, 1e-3}); failures++; }
+    catch (const std::invalid_argument&) {}
+  }
   std::printf(failures ? "ref_link FAILED (%d)\n" : "ref_link ok\n", failures);
   return failures;
 }
