@@ -705,8 +705,13 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
     STAGE(launch_scan_offsets(fp, g, cnt, chunk_first, im.ranges, im.rangesB, b.tsort.counts, ch.near_budget,
                               ch.phase == 1 ? c.mailbox_dev + 2 : nullptr, c.ticket, ch.phase == 1 ? c.top_hist : nullptr,
                               ch.phase == 1 ? dord.near_order : g.order, ch.phase == 1 && dord.partial, stream));
+  // bucket form of the tile sort (gsr_internal.hpp): first pass on the top eight bits, then one launch per chain that
+  // finishes every bucket and writes the ranges
+  const bool buckets = tile_sort_buckets(tile_bits, key16, cnt.cap);
+  const uint32_t shift0 = buckets ? (uint32_t)(tile_bits - 8) : 0u;
+  const uint32_t mask0 = buckets ? 255u : (1u << sort_digit_bits(tile_bits)) - 1u;
   STAGE(launch_emit(fp, sdesc, cnt, chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? point_list : b.ivalsB,
-                    inst_flag, b.tsort.counts, (1u << sort_digit_bits(tile_bits)) - 1u, key16,
+                    inst_flag, b.tsort.counts, shift0, mask0, key16,
                     /*store_pairs=*/!key16, stream));  // 16-bit keys: the pairs are generated inside the first sort pass
   const EmitFusion ef = {fp, sdesc, cnt, chunk_first};
   // 16-bit keys and at least two passes: the last pass counts the instances of every tile into the zeroed ranges
@@ -714,10 +719,13 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
   // kernel reads the sorted keys as the reference's identifyTileRanges does
   static const bool ranges_from_keys = getenv("GSR_RANGES_FROM_KEYS") != nullptr;  // diagnostics / fallback
   const bool count_ranges = key16 && sort_passes(tile_bits) >= 2 && !ranges_from_keys;
+  const BucketPass bp = {ranges, tiles, ch.base};
   STAGE(launch_sort_pairs(b.tkeysA, point_list, b.tkeysB, b.ivalsB, b.tsort, cnt, tile_bits, start_in_A,
                           /*is_depth_sort=*/false, key16, /*first_hist_done=*/true, key16 ? &ef : nullptr,
-                          count_ranges ? reinterpret_cast<uint32_t*>(ranges) : nullptr, stream));
-  if (count_ranges)
+                          count_ranges ? reinterpret_cast<uint32_t*>(ranges) : nullptr, stream, buckets ? &bp : nullptr));
+  if (buckets) {
+    // (the ranges are written by the bucket pass)
+  } else if (count_ranges)
     STAGE(launch_ranges_from_counts(ranges, tiles, ch.base, cnt, stream));
   else
     STAGE(launch_tile_ranges(b.tkeysA, cnt, ranges, key16, ch.base, stream));

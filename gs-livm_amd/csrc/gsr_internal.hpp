@@ -311,9 +311,11 @@ hipError_t launch_clear_words(Count gate, uint32_t* words, size_t n, hipStream_t
 hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, Count capB, uint32_t slot_base, const uint32_t* sat,
                                    uint32_t* chunk_firstB, uint32_t* counts0, unsigned long long* publish,
                                    uint32_t ticket, hipStream_t s);
+// (digit_shift0 / digit_mask0: the digit of the tile sort's first pass, whose per-sort-tile counts the emitter leaves in
+// counts0 -- the low bits of the tile id for the LSD sort, its top eight bits for the bucket sort, see tile_sort_buckets)
 hipError_t launch_emit(const FrameParams& fp, const uint4* sdesc, Count R, uint32_t* chunk_first, uint32_t* tkeys_out,
-                       uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_mask0, bool key16,
-                       bool store_pairs, hipStream_t s);
+                       uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_shift0,
+                       uint32_t digit_mask0, bool key16, bool store_pairs, hipStream_t s);
 // what k_emit_scatter (the tile sort's first pass with the pairs generated in place) needs from the emitter's side
 struct EmitFusion {
   FrameParams fp;
@@ -321,9 +323,21 @@ struct EmitFusion {
   Count R;
   const uint32_t* chunk_first;
 };
-hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_t* vals_out, int nbits0,
+hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_t* vals_out, int shift0, int nbits0,
                                const uint32_t* counts, const uint32_t* chunk_base, const uint32_t* digit_total,
                                bool arank, hipStream_t s);
+// Bucket form of the 16-bit tile sort (radix_sort.hip): the first pass partitions the instances by the TOP eight bits of
+// the tile id (stable), then ONE launch finishes every bucket on its own -- a workgroup counts its bucket's low digits,
+// scatters it stably and writes the ranges of its tiles: the second pass's histogram, scan and range launches are gone
+// (7 launches -> 4 per chain).  A bucket is one workgroup's serial job, so sorts beyond TILE_SORT_BUCKETS_MAX pairs
+// (one-chain frames of dense 1080p scenes) keep the two LSD passes, as do 32-bit keys and single-pass sorts.
+constexpr int TILE_SORT_BUCKETS_MAX = 16 << 20;
+bool tile_sort_buckets(int tile_bits, bool key16, int capacity);
+struct BucketPass {
+  uint2* ranges;        // the chain's tile ranges (written in full: (0, 0) for tiles without instances)
+  int tiles;
+  uint32_t list_base;   // first list position of the chain (a far chain's lists start behind the near capacity)
+};
 // (split_frame: a near/far frame -- the Gaussians with records are looked for among the emitted ones' descriptors)
 hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningState b, float* dL_dmean2D,
                                  float* dL_dconic, float* dL_dopacity, float* dL_dcolor, bool split_frame,
@@ -333,7 +347,7 @@ hipError_t launch_gather_records(const FrameParams& fp, GeomState g, BinningStat
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
                              Count n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
                              bool first_hist_done, const EmitFusion* fused_first_pass, uint32_t* key_count,
-                             hipStream_t s);
+                             hipStream_t s, const BucketPass* buckets = nullptr);
 // (n.dev != nullptr: the pair count is read on the device -- the near sort of a partial depth sort, whose tile size is
 // that of a sort of n.cap pairs so that both use the scratch alike; n.gate: the gated full sort of an asynchronous
 // frame's far chain)

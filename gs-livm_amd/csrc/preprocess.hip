@@ -1117,7 +1117,8 @@ template <bool ARANK>
 __global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, const uint4* __restrict__ sdesc, const Count cnt,
                                                       const uint32_t* __restrict__ chunk_first,
                                                       uint16_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out,
-                                                      const int nbits0, const uint32_t* __restrict__ counts,
+                                                      const int shift0, const int nbits0,
+                                                      const uint32_t* __restrict__ counts,
                                                       const uint32_t* __restrict__ chunk_base,
                                                       const uint32_t* __restrict__ digit_total) {
   static_assert(TSORT_TILE == 2 * EMIT_CHUNK && TSORT_WAVES == 4, "one sort tile = two emit chunks on 256 threads");
@@ -1173,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_emit_scatter(const FrameParams fp, cons
     val[s] = valid ? sm.L.lval[p] : 0u;
   }
   __syncthreads();
-  scatter_core<uint16_t, false, ARANK, TSORT_WAVES, TSORT_TILE>(sm.L, key, val, tile, keys_out, vals_out, R, 0, nbits0,
+  scatter_core<uint16_t, false, ARANK, TSORT_WAVES, TSORT_TILE>(sm.L, key, val, tile, keys_out, vals_out, R, shift0, nbits0,
                                                                 counts, chunk_base, digit_total, nullptr);
   });
 }
@@ -1184,7 +1185,7 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, const uint4*
                                               const uint32_t* __restrict__ chunk_first,
                                               K* __restrict__ tkeys_out, uint32_t* __restrict__ ivals_out,
                                               uint8_t* __restrict__ inst_flag, uint32_t* __restrict__ counts0,
-                                              const uint32_t digit_mask0) {
+                                              const uint32_t digit_shift0, const uint32_t digit_mask0) {
   __shared__ EmitStage st;
   __shared__ uint32_t hist[256];  // digit counts of the tile sort's FIRST pass for this workgroup's 2048 slots
   const int tid = threadIdx.x;
@@ -1230,7 +1231,7 @@ __global__ __launch_bounds__(256) void k_emit(const FrameParams fp, const uint4*
   }
 #pragma unroll
   for (int k = 0; k < 8; k++)
-    if (t0 + (uint32_t)k < c1) atomicAdd(&hist[tk[k] & digit_mask0], 1u);
+    if (t0 + (uint32_t)k < c1) atomicAdd(&hist[(tk[k] >> digit_shift0) & digit_mask0], 1u);
   }
   // The sort's first pass needs digit counts per sort tile: several emitting workgroups share one, so each adds
   // its non-zero bins (k_scan_offsets cleared the array) -- this replaces a histogram pass over all the keys.
@@ -1763,34 +1764,34 @@ hipError_t launch_scan_offsets_far(const FrameParams& fp, GeomState g, Count cap
 }
 
 hipError_t launch_emit(const FrameParams& fp, const uint4* sdesc, Count R, uint32_t* chunk_first, uint32_t* tkeys_out,
-                       uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_mask0, bool key16,
-                       bool store_pairs, hipStream_t s) {
+                       uint32_t* ivals_out, uint8_t* inst_flag, uint32_t* counts0, uint32_t digit_shift0,
+                       uint32_t digit_mask0, bool key16, bool store_pairs, hipStream_t s) {
   if (R.cap <= 0) return hipSuccess;
   ProfScope ps(K_EMIT, s);
   const dim3 grid(chain_grid(R, EMIT_CHUNK));
   if (key16 && store_pairs)
     hipLaunchKernelGGL((k_emit<uint16_t, true>), grid, dim3(256), 0, s, fp, sdesc, R, chunk_first,
-                       reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_mask0);
+                       reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_shift0, digit_mask0);
   else if (key16)
     hipLaunchKernelGGL((k_emit<uint16_t, false>), grid, dim3(256), 0, s, fp, sdesc, R, chunk_first,
-                       reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_mask0);
+                       reinterpret_cast<uint16_t*>(tkeys_out), ivals_out, inst_flag, counts0, digit_shift0, digit_mask0);
   else
     hipLaunchKernelGGL((k_emit<uint32_t, true>), grid, dim3(256), 0, s, fp, sdesc, R, chunk_first, tkeys_out, ivals_out,
-                       inst_flag, counts0, digit_mask0);
+                       inst_flag, counts0, digit_shift0, digit_mask0);
   return hipGetLastError();
 }
 
 // first pass of the 16-bit tile sort with the pairs generated in place (see k_emit_scatter)
-hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_t* vals_out, int nbits0,
+hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_t* vals_out, int shift0, int nbits0,
                                const uint32_t* counts, const uint32_t* chunk_base, const uint32_t* digit_total,
                                bool arank, hipStream_t s) {
   const dim3 grid(chain_grid(ef.R, TSORT_TILE));
   if (arank)
     hipLaunchKernelGGL(k_emit_scatter<true>, grid, dim3(256), 0, s, ef.fp, ef.sdesc, ef.R, ef.chunk_first, keys_out, vals_out,
-                       nbits0, counts, chunk_base, digit_total);
+                       shift0, nbits0, counts, chunk_base, digit_total);
   else
     hipLaunchKernelGGL(k_emit_scatter<false>, grid, dim3(256), 0, s, ef.fp, ef.sdesc, ef.R, ef.chunk_first, keys_out,
-                       vals_out, nbits0, counts, chunk_base, digit_total);
+                       vals_out, shift0, nbits0, counts, chunk_base, digit_total);
   return hipGetLastError();
 }
 

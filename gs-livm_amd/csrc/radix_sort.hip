@@ -252,12 +252,165 @@ hipError_t launch_verify_sorted_lists(const uint2* ranges, int T, const uint32_t
   return hipGetLastError();
 }
 
+// Second and last pass of the bucket form of the tile sort (gsr_internal.hpp, tile_sort_buckets).  The first pass has
+// partitioned the pairs, stably, by the top eight bits of the 16-bit tile id: bucket b is the contiguous run of
+// digit_total[b] pairs behind the buckets below it, in emission (= depth) order.  One 1024-thread workgroup per bucket
+// holds up to 16 384 pairs in registers (16 per thread, lane = consecutive pair: coalesced loads, all in flight at
+// once).  Ranking the pairs inside their wave -- ONE returning LDS add per 64 pairs on a per-wave table of the bucket's
+// <= 256 tiles where the probe allows (sort_core.hpp, ARANK), a ballot match otherwise -- leaves the tables holding the
+// per-wave counts, i.e. the bucket's histogram as well: thread = tile sums them, the bucket's 256 counts are scanned,
+// the RANGES of its tiles are written -- (0, 0) for tiles without instances, the reference's memset
+// (rasterizer_impl.cu:311) -- and every pair goes to segment start + (pairs of earlier waves) + rank.  A bucket that
+// does not fit (sorts of several million pairs per chain) is counted in a first sweep and scattered chunk by chunk in
+// a second.  What a classic pass needs k_sort_hist + k_sort_scan_columns + k_sort_scatter<COUNT> +
+// k_ranges_from_counts for stays inside one workgroup.  Output = the reference's list order (tile, depth bits,
+// Gaussian id), bit for bit.
+constexpr int BUCKET_THREADS = 1024, BUCKET_WAVES = BUCKET_THREADS / 64, BUCKET_ITEMS = 16;
+constexpr int BUCKET_CHUNK = BUCKET_THREADS * BUCKET_ITEMS;
+
+// exclusive scan of one value per thread of the FIRST 256 threads of a 1024-thread workgroup (every thread calls it)
+__device__ __forceinline__ uint32_t bucket_excl_scan_256(uint32_t v, int tid, uint32_t* wtot /*[4]*/) {
+  const int lane = tid & 63, w = tid >> 6;
+  const uint32_t inc = tid < 256 ? wave_incl_scan(v, lane) : 0u;
+  if (tid < 256 && lane == 63) wtot[w] = inc;
+  __syncthreads();
+  uint32_t o = 0;
+  if (tid < 256)
+    for (int k = 0; k < w; k++) o += wtot[k];
+  __syncthreads();
+  return o + inc - v;
+}
+
+template <bool ARANK>
+__global__ __launch_bounds__(BUCKET_THREADS) void k_bucket_sort(const uint16_t* __restrict__ keys,
+                                                                const uint32_t* __restrict__ vals,
+                                                                uint32_t* __restrict__ out, const Count cnt,
+                                                                const uint32_t* __restrict__ digit_total,
+                                                                const int lowbits, const int T,
+                                                                uint2* __restrict__ ranges, const uint32_t list_base) {
+  __shared__ uint32_t wcnt[BUCKET_WAVES][256];  // per-wave tile counts of the chunk, then per-wave write positions
+  __shared__ uint32_t hist[256], run[256], wtot[4];
+  // a bucket that fits one chunk is brought into its final order HERE and written out in one coalesced sweep (64
+  // scattered 4-byte stores per wave instruction measured 3x the time of the whole rest of the kernel)
+  __shared__ uint32_t lval[BUCKET_CHUNK];
+  __shared__ uint32_t s_start, s_count;
+  if (cnt.closed()) return;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const uint32_t lowmask = (1u << lowbits) - 1u;
+  for (int b = blockIdx.x; b < 256; b += gridDim.x) {
+    {
+      const uint32_t dt = tid < 256 ? digit_total[tid] : 0u;
+      const uint32_t ex = bucket_excl_scan_256(dt, tid, wtot);
+      if (tid == b) { s_start = ex; s_count = dt; }
+      if (tid < 256) hist[tid] = 0u;
+      __syncthreads();
+    }
+    const uint32_t start = s_start, count = s_count;
+    const bool one_chunk = count <= (uint32_t)BUCKET_CHUNK;  // (workgroup-uniform)
+    if (!one_chunk) {  // first sweep: the bucket's histogram
+      for (uint32_t c0 = 0; c0 < count; c0 += BUCKET_CHUNK) {
+        uint32_t k16[BUCKET_ITEMS];
+#pragma unroll
+        for (int s = 0; s < BUCKET_ITEMS; s++) {
+          const uint32_t i = c0 + (uint32_t)(w * (BUCKET_ITEMS * 64) + s * 64 + lane);
+          k16[s] = i < count ? (uint32_t)keys[start + i] & lowmask : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int s = 0; s < BUCKET_ITEMS; s++)
+          if (k16[s] != 0xFFFFFFFFu) atomicAdd(&hist[k16[s]], 1u);
+      }
+      __syncthreads();
+      const uint32_t c = tid < 256 ? hist[tid] : 0u;
+      const uint32_t o = bucket_excl_scan_256(c, tid, wtot);
+      if (tid < 256) {
+        run[tid] = start + o;  // next free position of this tile's segment
+        const uint32_t t = ((uint32_t)b << lowbits) | (uint32_t)tid;
+        if ((uint32_t)tid <= lowmask && t < (uint32_t)T)
+          ranges[t] = c ? make_uint2(list_base + start + o, list_base + start + o + c) : make_uint2(0u, 0u);
+      }
+      __syncthreads();
+    }
+    for (uint32_t c0 = 0; c0 < count || (one_chunk && c0 == 0); c0 += BUCKET_CHUNK) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) wcnt[w][lane + 64 * k] = 0u;  // (this wave's own table; others read it behind a barrier)
+      uint32_t d[BUCKET_ITEMS], v[BUCKET_ITEMS], lrank[BUCKET_ITEMS];
+#pragma unroll
+      for (int s = 0; s < BUCKET_ITEMS; s++) {
+        const uint32_t i = c0 + (uint32_t)(w * (BUCKET_ITEMS * 64) + s * 64 + lane);
+        const bool valid = i < count;
+        d[s] = valid ? (uint32_t)keys[start + i] & lowmask : 0xFFFFFFFFu;
+        v[s] = valid ? vals[start + i] : 0u;
+      }
+      volatile uint32_t* my = wcnt[w];
+#pragma unroll
+      for (int s = 0; s < BUCKET_ITEMS; s++) {
+        const bool valid = d[s] != 0xFFFFFFFFu;
+        if (ARANK) {  // (lanes of one ds_add_rtn that hit one address are served in lane order -- probed once per process)
+          lrank[s] = valid ? __hip_atomic_fetch_add(&wcnt[w][d[s]], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) : 0u;
+        } else {
+          const uint64_t m = match_digit(valid ? d[s] : 0u, valid, lowbits);
+          const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt(lane));
+          const uint32_t prior = my[valid ? d[s] : 0u];
+          if (valid && rank == 0) my[d[s]] = prior + (uint32_t)__popcll(m);
+          lrank[s] = prior + rank;
+        }
+      }
+      __syncthreads();
+      if (one_chunk) {  // the per-wave counts ARE the bucket's histogram: scan it and write the ranges
+        uint32_t c = 0;
+        if (tid < 256)
+          for (int k = 0; k < BUCKET_WAVES; k++) c += wcnt[k][tid];
+        const uint32_t o = bucket_excl_scan_256(c, tid, wtot);
+        if (tid < 256) {
+          run[tid] = start + o;
+          const uint32_t t = ((uint32_t)b << lowbits) | (uint32_t)tid;
+          if ((uint32_t)tid <= lowmask && t < (uint32_t)T)
+            ranges[t] = c ? make_uint2(list_base + start + o, list_base + start + o + c) : make_uint2(0u, 0u);
+        }
+      }
+      if (tid < 256) {  // thread = tile of the bucket: where each wave's pairs of this chunk go
+        uint32_t pos = run[tid];
+#pragma unroll
+        for (int k = 0; k < BUCKET_WAVES; k++) {
+          const uint32_t n = wcnt[k][tid];
+          wcnt[k][tid] = pos;
+          pos += n;
+        }
+        run[tid] = pos;
+      }
+      __syncthreads();
+      if (one_chunk) {
+#pragma unroll
+        for (int s = 0; s < BUCKET_ITEMS; s++)
+          if (d[s] != 0xFFFFFFFFu) lval[wcnt[w][d[s]] + lrank[s] - start] = v[s];
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < BUCKET_ITEMS; s++) {
+          const uint32_t i = (uint32_t)(s * BUCKET_THREADS + tid);
+          if (i < count) out[start + i] = lval[i];
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < BUCKET_ITEMS; s++)
+          if (d[s] != 0xFFFFFFFFu) out[wcnt[w][d[s]] + lrank[s]] = v[s];
+      }
+      __syncthreads();
+    }
+  }
+}
+
+bool tile_sort_buckets(int tile_bits, bool key16, int capacity) {
+  static const bool lsd = getenv("GSR_TILE_SORT_LSD") != nullptr;  // diagnostics / fallback: always the two LSD passes
+  return key16 && !lsd && tile_bits > 8 && sort_passes(tile_bits) == 2 && capacity <= TILE_SORT_BUCKETS_MAX;
+}
+
 // The pairs start in (keysA, valsA) when start_in_A, else in (keysB, valsB); passes alternate.  The caller
 // picks start_in_A = (passes even) so the result always lands in (keysA, valsA).
 template <typename K>
 static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t* valsB, SortScratch sc, Count cnt,
                                   int end_bit, bool start_in_A, bool is_depth_sort, bool first_hist_done,
-                                  const EmitFusion* ef, uint32_t* key_count, hipStream_t s) {
+                                  const EmitFusion* ef, uint32_t* key_count, hipStream_t s,
+                                  const BucketPass* buckets = nullptr) {
   const int kb = is_depth_sort ? (int)K_DSORT_HIST - (int)K_SORT_HIST : 0;  // profiler ids of this sort
   // tile geometry of the instance sort (both key widths use the same today; see TSORT_TILE)
   constexpr int TT = sizeof(K) == 2 ? TSORT_TILE : SORT_TILE, NWV = sizeof(K) == 2 ? TSORT_WAVES : 4;
@@ -270,6 +423,45 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
   const bool arank = lds_atomic_rank_ok(s);
   static const bool two_level_scan = getenv("GSR_SORT_TWO_LEVEL_SCAN") != nullptr;  // diagnostics / fallback
   bool inA = start_in_A;
+  if (buckets && sizeof(K) == 2 && ef && first_hist_done) {
+    // bucket form: first pass = the fused emit-scatter on the TOP eight bits (its counts came from the emitter), second
+    // pass = one launch that finishes every bucket and writes the ranges
+    const int lowbits = end_bit - 8;
+    const bool one_scan = ntiles <= SCAN_COLUMNS_MAX && !two_level_scan;
+    const uint32_t* chunk_base = one_scan ? nullptr : sc.chunk_sums;
+    if (one_scan) {
+      ProfScope ps(K_SORT_SCAN_CHUNKS, s);
+      hipLaunchKernelGGL(k_sort_scan_columns, dim3(64), dim3(256), 0, s, sc.counts, ntiles, sc.digit_base, cnt);
+    } else {
+      {
+        ProfScope ps(K_SORT_SCAN_CHUNKS, s);
+        hipLaunchKernelGGL(k_sort_scan_chunks, dim3(nchunks), dim3(256), 0, s, sc.counts, ntiles, sc.chunk_sums, cnt);
+      }
+      {
+        ProfScope ps(K_SORT_SCAN_TOP, s);
+        hipLaunchKernelGGL(k_sort_scan_top, dim3(64), dim3(256), 0, s, sc.chunk_sums, nchunks, sc.digit_base, cnt);
+      }
+    }
+    K* kmid = inA ? keysB : keysA;
+    uint32_t* vmid = inA ? valsB : valsA;
+    uint32_t* vfin = inA ? valsA : valsB;
+    {
+      ProfScope ps(K_SORT_SCATTER, s);
+      const hipError_t e = launch_emit_scatter(*ef, reinterpret_cast<uint16_t*>(kmid), vmid, lowbits, 8, sc.counts,
+                                               chunk_base, sc.digit_base, arank, s);
+      if (e != hipSuccess) return e;
+    }
+    {
+      ProfScope ps(K_TILE_RANGES, s);  // (booked where the range step was: it now holds the whole second pass)
+      if (arank)
+        hipLaunchKernelGGL(k_bucket_sort<true>, dim3(256), dim3(BUCKET_THREADS), 0, s, reinterpret_cast<const uint16_t*>(kmid), vmid,
+                           vfin, cnt, sc.digit_base, lowbits, buckets->tiles, buckets->ranges, buckets->list_base);
+      else
+        hipLaunchKernelGGL(k_bucket_sort<false>, dim3(256), dim3(BUCKET_THREADS), 0, s, reinterpret_cast<const uint16_t*>(kmid), vmid,
+                           vfin, cnt, sc.digit_base, lowbits, buckets->tiles, buckets->ranges, buckets->list_base);
+    }
+    return hipGetLastError();
+  }
   for (int p = 0; p < passes; p++) {
     const K* kin = inA ? keysA : keysB;
     const uint32_t* vin = inA ? valsA : valsB;
@@ -297,7 +489,7 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
     }
     if (p == 0 && ef && sizeof(K) == 2) {  // the emitter generates the pairs inside the first pass
       ProfScope ps(K_SORT_SCATTER + kb, s);
-      const hipError_t e = launch_emit_scatter(*ef, reinterpret_cast<uint16_t*>(kout), vout, nbits, sc.counts,
+      const hipError_t e = launch_emit_scatter(*ef, reinterpret_cast<uint16_t*>(kout), vout, 0, nbits, sc.counts,
                                                chunk_base, sc.digit_base, arank, s);
       if (e != hipSuccess) return e;
     } else if (key_count && p == passes - 1 && p > 0 && sizeof(K) == 2) {
@@ -332,12 +524,12 @@ static hipError_t sort_pairs_impl(K* keysA, uint32_t* valsA, K* keysB, uint32_t*
 hipError_t launch_sort_pairs(uint32_t* keysA, uint32_t* valsA, uint32_t* keysB, uint32_t* valsB, SortScratch sc,
                              Count n, int end_bit, bool start_in_A, bool is_depth_sort, bool key16,
                              bool first_hist_done, const EmitFusion* fused_first_pass, uint32_t* key_count,
-                             hipStream_t s) {
+                             hipStream_t s, const BucketPass* buckets) {
   if (n.cap <= 0) return hipSuccess;
   if (key16)
     return sort_pairs_impl<uint16_t>(reinterpret_cast<uint16_t*>(keysA), valsA, reinterpret_cast<uint16_t*>(keysB),
                                      valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done, fused_first_pass,
-                                     key_count, s);
+                                     key_count, s, buckets);
   return sort_pairs_impl<uint32_t>(keysA, valsA, keysB, valsB, sc, n, end_bit, start_in_A, is_depth_sort, first_hist_done,
                                    nullptr, nullptr, s);
 }

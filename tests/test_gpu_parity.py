@@ -754,13 +754,17 @@ def test_product_sh_variants_against_the_oracle(D, mode, gpu_device):
         grad_close(got[k], ref[k], k, outlier_frac=2e-6)
 
 
-@pytest.mark.parametrize("knob", ["GSR_SORT_BALLOT_RANK", "GSR_DEPTH_HIST_PASS", "GSR_RANGES_FROM_KEYS",
-                                  "GSR_SORT_TWO_LEVEL_SCAN"])
+@pytest.mark.parametrize("knob", ["GSR_SORT_BALLOT_RANK", "GSR_DEPTH_HIST_PASS", "GSR_TILE_SORT_LSD",
+                                  "GSR_TILE_SORT_LSD,GSR_SORT_BALLOT_RANK", "GSR_TILE_SORT_LSD,GSR_RANGES_FROM_KEYS",
+                                  "GSR_SORT_TWO_LEVEL_SCAN", "GSR_TILE_SORT_LSD,GSR_SORT_TWO_LEVEL_SCAN"])
 def test_sort_fallback_paths(knob, gpu_device):
     """The radix scatter ranks with returning LDS atomics only after a one-time probe of the hardware's conflict
     order; GSR_SORT_BALLOT_RANK=1 forces the ballot-match variant the library falls back to.  GSR_DEPTH_HIST_PASS=1
     makes the depth sort count its digits itself instead of taking the histograms k_preprocess counted;
-    GSR_RANGES_FROM_KEYS=1 derives the tile ranges from the sorted keys instead of the last pass's counts;
+    GSR_TILE_SORT_LSD=1 sorts the instances in two LSD passes (histogram, scan, scatter each + a range kernel: what
+    sorts beyond 16 M pairs and 32-bit keys take) instead of the bucket form (top eight bits, then one launch that
+    finishes every bucket and writes the ranges); with it, GSR_RANGES_FROM_KEYS=1 derives the tile ranges from the
+    sorted keys instead of the last pass's counts;
     GSR_SORT_TWO_LEVEL_SCAN=1 scans the tile sort's digit counts in two launches as sorts beyond 8 M pairs do.  All are
     read once per process, so the check runs in a child process: bit-exact lists against the oracle there too
     (three forwards: the library-owned histogram buffers alternate between calls)."""
@@ -782,7 +786,7 @@ def test_sort_fallback_paths(knob, gpu_device):
         "    assert fwd[0] == fr.R and np.array_equal(u(v['point_list']), fr.point_list)\n"
         "    assert np.array_equal(u(v['ranges']), fr.ranges)\n"
         "print('fallback ok')\n") % (os.path.dirname(GOLDEN.rstrip('/').rsplit('/', 1)[0]), os.path.dirname(GOLDEN))
-    env = dict(os.environ, **{knob: "1"})
+    env = dict(os.environ, **{k: "1" for k in knob.split(",")})
     out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "fallback ok" in out.stdout, out.stderr[-2000:]
 
