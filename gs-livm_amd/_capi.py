@@ -242,10 +242,11 @@ def rasterize_forward(background, means3D, colors, opacity, scales, rotations, s
 
 def rasterize_backward(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
                        viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_acc, sh, degree, campos,
-                       geomBuffer, R, binningBuffer, imageBuffer, debug=False, return_conic=False):
+                       geomBuffer, R, binningBuffer, imageBuffer, debug=False, return_conic=False, want_cov3D=True):
     """Mirror of RasterizeGaussiansBackwardCUDA (src/gs/rasterize_points.cu:132-224).
     Returns (dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales, dL_drotations)
-    [+ dL_dconic when return_conic]."""
+    [+ dL_dconic when return_conic].  want_cov3D=False (only without cov3D_precomp): dL_dcov3D -- then an intermediate
+    nobody reads -- is neither allocated nor written and comes back as None."""
     dev = means3D.device
     P = int(means3D.size(0))
     H, W = int(dL_dout_color.size(1)), int(dL_dout_color.size(2))
@@ -259,7 +260,7 @@ def rasterize_backward(background, means3D, radii, colors, scales, rotations, sc
     dL_dcolors = mk((P, 3), **f32)
     dL_dconic = mk((P, 2, 2), **f32)
     dL_dopacity = mk((P, 1), **f32)
-    dL_dcov3D = mk((P, 6), **f32)
+    dL_dcov3D = mk((P, 6), **f32) if want_cov3D else None
     dL_dsh = mk((P, M, 3), **f32)
     dL_dscales = mk((P, 3), **f32)
     dL_drotations = mk((P, 4), **f32)

@@ -1214,8 +1214,10 @@ int gsr_backward(int P, int D, int M, int R, const float* background, int width,
   if (!geom_buffer || !binning_buffer || !image_buffer) return fail(GSR_ERR_INVALID_ARGUMENT, "null state blob");
   if (!means3D || !background || !viewmatrix || !projmatrix || !campos || !dL_dpix || !dL_dacc)
     return fail(GSR_ERR_INVALID_ARGUMENT, "null required input");
-  if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || !dL_dcov3D || !dL_dscale || !dL_drot ||
-      (M > 0 && !dL_dsh))
+  // (dL_dcov3D may be NULL when the covariance is computed from scales and rotations: it is then an intermediate nobody
+  // reads, and 24 of the kernel's 218 bytes per Gaussian are not written)
+  if (!dL_dmean2D || !dL_dconic || !dL_dopacity || !dL_dcolor || !dL_dmean3D || (!dL_dcov3D && cov3D_precomp) ||
+      !dL_dscale || !dL_drot || (M > 0 && !dL_dsh))
     return fail(GSR_ERR_INVALID_ARGUMENT, "null gradient output");
   static const bool host_trace_b = getenv("GSR_HOST_TRACE") != nullptr;
   if (host_trace_b)

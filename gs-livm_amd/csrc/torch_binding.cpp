@@ -105,16 +105,19 @@ RasterizeGaussiansCUDA(const torch::Tensor& background, const torch::Tensor& mea
   return std::make_tuple(rendered, out_color, out_depth, out_acc, radii, geomBuffer, binningBuffer, imgBuffer);
 }
 
-std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
-           torch::Tensor>
-RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
-                               const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
-                               const float scale_modifier, const torch::Tensor& cov3D_precomp,
-                               const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
-                               const float tan_fovy, const torch::Tensor& dL_dout_color,
-                               const torch::Tensor& dL_dout_acc, const torch::Tensor& sh, const int degree,
-                               const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
-                               const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug) {
+// want_cov3D = false (the autograd node, when the covariance comes from scales and rotations): dL_dcov3D is an
+// intermediate nobody reads -- it is neither allocated nor written (24 of the 218 bytes per Gaussian the per-Gaussian
+// backward moves) and comes back undefined.  The public entry point always returns it, as the reference does.
+static std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+                  torch::Tensor>
+rasterize_backward_impl(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                        const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
+                        const float scale_modifier, const torch::Tensor& cov3D_precomp, const torch::Tensor& viewmatrix,
+                        const torch::Tensor& projmatrix, const float tan_fovx, const float tan_fovy,
+                        const torch::Tensor& dL_dout_color, const torch::Tensor& dL_dout_acc, const torch::Tensor& sh,
+                        const int degree, const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                        const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug,
+                        const bool want_cov3D) {
   const int P = means3D.size(0);
   const int H = dL_dout_color.size(1);
   const int W = dL_dout_color.size(2);
@@ -127,7 +130,7 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
   torch::Tensor dL_dcolors = mk({P, 3});
   torch::Tensor dL_dconic = mk({P, 2, 2});
   torch::Tensor dL_dopacity = mk({P, 1});
-  torch::Tensor dL_dcov3D = mk({P, 6});
+  torch::Tensor dL_dcov3D = want_cov3D ? mk({P, 6}) : torch::Tensor();
   torch::Tensor dL_dsh = mk({P, M, 3});
   torch::Tensor dL_dscales = mk({P, 3});
   torch::Tensor dL_drotations = mk({P, 4});
@@ -142,13 +145,29 @@ RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Ten
                        reinterpret_cast<char*>(binningBuffer.data_ptr()),
                        reinterpret_cast<char*>(imageBuffer.data_ptr()), fptr(dpix), fptr(dacc),
                        dL_dmeans2D.data_ptr<float>(), dL_dconic.data_ptr<float>(), dL_dopacity.data_ptr<float>(),
-                       dL_dcolors.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(), dL_dcov3D.data_ptr<float>(),
+                       dL_dcolors.data_ptr<float>(), dL_dmeans3D.data_ptr<float>(),
+                       dL_dcov3D.defined() ? dL_dcov3D.data_ptr<float>() : nullptr,
                        M ? dL_dsh.data_ptr<float>() : nullptr, dL_dscales.data_ptr<float>(),
                        dL_drotations.data_ptr<float>(), debug ? 1 : 0, current_stream()),
           "gsr_backward");
   }
   return std::make_tuple(dL_dmeans2D, dL_dcolors, dL_dopacity, dL_dmeans3D, dL_dcov3D, dL_dsh, dL_dscales,
                          dL_drotations);
+}
+
+std::tuple<torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor, torch::Tensor,
+           torch::Tensor>
+RasterizeGaussiansBackwardCUDA(const torch::Tensor& background, const torch::Tensor& means3D, const torch::Tensor& radii,
+                               const torch::Tensor& colors, const torch::Tensor& scales, const torch::Tensor& rotations,
+                               const float scale_modifier, const torch::Tensor& cov3D_precomp,
+                               const torch::Tensor& viewmatrix, const torch::Tensor& projmatrix, const float tan_fovx,
+                               const float tan_fovy, const torch::Tensor& dL_dout_color,
+                               const torch::Tensor& dL_dout_acc, const torch::Tensor& sh, const int degree,
+                               const torch::Tensor& campos, const torch::Tensor& geomBuffer, const int R,
+                               const torch::Tensor& binningBuffer, const torch::Tensor& imageBuffer, const bool debug) {
+  return rasterize_backward_impl(background, means3D, radii, colors, scales, rotations, scale_modifier, cov3D_precomp,
+                                 viewmatrix, projmatrix, tan_fovx, tan_fovy, dL_dout_color, dL_dout_acc, sh, degree, campos,
+                                 geomBuffer, R, binningBuffer, imageBuffer, debug, /*want_cov3D=*/true);
 }
 
 torch::Tensor markVisible(torch::Tensor& means3D, torch::Tensor& viewmatrix, torch::Tensor& projmatrix) {
@@ -218,13 +237,13 @@ torch::autograd::tensor_list _RasterizeGaussians::backward(torch::autograd::Auto
   if (!grad_acc.defined()) grad_acc = torch::zeros({1, H, W}, means3D.options());
   auto [grad_means2D, grad_colors_precomp, grad_opacities, grad_means3D, grad_cov3Ds_precomp, grad_sh, grad_scales,
         grad_rotations] =
-      RasterizeGaussiansBackwardCUDA(
+      rasterize_backward_impl(
           ctx->saved_data["background"].to<torch::Tensor>(), means3D, radii, colors_precomp, scales, rotations,
           ctx->saved_data["scale_modifier"].to<double>(), cov3Ds_precomp,
           ctx->saved_data["viewmatrix"].to<torch::Tensor>(), ctx->saved_data["projmatrix"].to<torch::Tensor>(),
           ctx->saved_data["tanfovx"].to<double>(), ctx->saved_data["tanfovy"].to<double>(), grad_out_color, grad_acc,
           sh, ctx->saved_data["sh_degree"].to<int>(), ctx->saved_data["camera_center"].to<torch::Tensor>(),
-          geomBuffer, num_rendered, binningBuffer, imgBuffer, false);
+          geomBuffer, num_rendered, binningBuffer, imgBuffer, false, /*want_cov3D=*/cov3Ds_precomp.numel() != 0);
   auto opt = [](const torch::Tensor& g, const torch::Tensor& x) { return x.numel() ? g : torch::Tensor(); };
   return {grad_means3D,
           grad_means2D,

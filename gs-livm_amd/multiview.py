@@ -95,13 +95,16 @@ def reduce_gradients(grad, dst=0, group=None, all_ranks=False):
     return grad
 
 
-def launch_local_ranks(argv, n_ranks, extra_env=None, timeout=None, out=None, err=None):
+def launch_local_ranks(argv, n_ranks, extra_env=None, timeout=3600.0, out=None, err=None):
     """One process per GPU on this node WITHOUT an external launcher: starts `n_ranks` children running `argv`
     (rank r gets RANK = LOCAL_RANK = r, WORLD_SIZE, MASTER_ADDR = 127.0.0.1 and a free MASTER_PORT -- what
     `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` would set), relays rank 0's
     stdout to `out` (default: this process's stdout) and every rank's stderr to `err`, and returns the exit status:
     0 only when every rank exited 0.  When a rank fails the others are terminated (by pid) so a dead peer cannot
-    leave them waiting in a collective.  The caller must not have touched the GPU: the children own the devices.
+    leave them waiting in a collective.  The pipes are drained WHILE the ranks run (a reader thread each): a rank that
+    writes more than a pipe buffer -- RCCL debug output, a long JSON line -- can never block on a parent that only reads
+    at the end.  `timeout` (seconds, default 3600; None = none): ranks still running then are killed, status 124.
+    The caller must not have touched the GPU: the children own the devices.
     """
     import os
     import socket
@@ -122,6 +125,19 @@ def launch_local_ranks(argv, n_ranks, extra_env=None, timeout=None, out=None, er
         env.update(extra_env or {})
         procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL,
                                       stderr=None if err is sys.stderr else subprocess.PIPE, text=True))
+    import threading
+    captured = {}
+
+    def drain(key, pipe):
+        captured[key] = pipe.read()  # (returns at EOF, i.e. when the child has closed its end)
+
+    readers = []
+    for r, p in enumerate(procs):
+        for key, pipe in ((("out", r), p.stdout), (("err", r), p.stderr)):
+            if pipe is not None:
+                th = threading.Thread(target=drain, args=(key, pipe), daemon=True)
+                th.start()
+                readers.append(th)
     t0 = time.monotonic()
     status = 0
     pending = set(range(n_ranks))
@@ -144,12 +160,14 @@ def launch_local_ranks(argv, n_ranks, extra_env=None, timeout=None, out=None, er
             timeout = None
         if pending:
             time.sleep(0.05)
-    text = procs[0].stdout.read() if procs[0].stdout else ""
+    for th in readers:
+        th.join(timeout=10.0)
+    text = captured.get(("out", 0)) or ""
     if text:
         out.write(text)
         out.flush()
     if err is not sys.stderr:
-        for p in procs:
-            if p.stderr:
-                err.write(p.stderr.read())
+        for r in range(n_ranks):
+            if captured.get(("err", r)):
+                err.write(captured[("err", r)])
     return status

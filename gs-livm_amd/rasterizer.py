@@ -60,7 +60,8 @@ class _RasterizeGaussians(torch.autograd.Function):
             s.bg, means3D.contiguous(), radii, colors_precomp.contiguous(), scales.contiguous(),
             rotations.contiguous(), s.scale_modifier, cov3Ds_precomp.contiguous(), s.viewmatrix.contiguous(),
             s.projmatrix.contiguous(), s.tanfovx, s.tanfovy, grad_color, grad_acc, sh.contiguous(), s.sh_degree,
-            s.camera_center.contiguous(), geom, ctx.num_rendered, binning, img, False)
+            s.camera_center.contiguous(), geom, ctx.num_rendered, binning, img, False,
+            want_cov3D=cov3Ds_precomp.numel() != 0)
         none_if_empty = lambda g, x: g if x.numel() else None  # noqa: E731
         return (g_means3D, g_means2D, none_if_empty(g_sh, sh), none_if_empty(g_colors, colors_precomp), g_opac,
                 none_if_empty(g_scales, scales), none_if_empty(g_rot, rotations),

@@ -180,6 +180,8 @@ int gsr_near_far_pause(int frames);
  * rasterize_points.cu:173-181; zeroed buffers remain valid input).
  *   dL_dmean2D [P][3] (.x,.y written, .z = 0), dL_dconic [P][4] (.x,.y,.w; .z = 0),
  *   dL_dopacity [P], dL_dcolor [P][3], dL_dmean3D [P][3], dL_dcov3D [P][6],
+ *   (dL_dcov3D may be NULL when cov3D_precomp is NULL: the gradient w.r.t. a covariance the library computed
+ *   itself from scales and rotations is an intermediate; it is then not written),
  *   dL_dsh [P][M][3], dL_dscale [P][3], dL_drot [P][4].
  * The gradient w.r.t. depth is not an input, exactly as in the reference
  * (src/gs/rasterizer.cu:79; backward.cu:451-452). */

@@ -1176,3 +1176,22 @@ def test_c4_eight_views_forward_parity(gpu_device):
             check_forward(sc, fr, fwd, gpu_device, debug=False)
             assert fr.R > 10_000_000
             del fr, t, fwd
+
+
+def test_backward_without_the_covariance_gradient(gpu_device):
+    """dL_dcov3D may be NULL when the covariance comes from scales and rotations (include/gsraster.h, gsr_backward): it
+    is then an intermediate nobody reads, and the operator's autograd node does not have it written.  Every other
+    gradient is bit-identical to the call that asks for it."""
+    sc = S.make_scene(20_000, 320, 200, 8, sh_degree=1)
+    t, fwd = hip_forward(sc, gpu_device, debug=False)
+    R, color, depth, acc, radii, geom, binning, img = fwd
+    dcol, dacc = S.make_upstream_grads(320, 200, 8)
+    args = (t["bg"], t["means3D"], radii, t["colors_precomp"], t["scales"], t["rotations"], 1.0, t["cov3D_precomp"],
+            t["viewmatrix"], t["projmatrix"], sc["tanfovx"], sc["tanfovy"], torch.from_numpy(dcol).to(gpu_device),
+            torch.from_numpy(dacc).to(gpu_device), t["shs"], 1, t["campos"], geom, R, binning, img, False)
+    full = G.rasterize_backward(*args)
+    lean = G.rasterize_backward(*args, want_cov3D=False)
+    assert lean[4] is None and full[4].abs().max() > 0
+    for k, (a, b) in enumerate(zip(full, lean)):
+        if k != 4:
+            assert torch.equal(a, b), k

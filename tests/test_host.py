@@ -235,6 +235,26 @@ def test_launch_local_ranks_reports_a_failed_rank():
     assert rc == 3 and time.time() - t0 < 30
 
 
+def test_launch_local_ranks_drains_the_pipes_while_the_ranks_run():
+    """A rank that writes far more than a pipe buffer (64 KB) to stdout and stderr -- RCCL debug output, a long JSON
+    line -- must not block on a parent that reads only when everyone has exited; and a rank that never ends is
+    killed at the timeout (status 124)."""
+    import io
+    import sys
+    import time
+    chatty = ("import os, sys\n"
+              "sys.stderr.write('e' * 300000 + '\\n'); sys.stderr.flush()\n"
+              "if os.environ['RANK'] == '0': sys.stdout.write('{\"pad\": \"' + 'x' * 400000 + '\"}\\n')\n")
+    out, err = io.StringIO(), io.StringIO()
+    t0 = time.time()
+    assert MV.launch_local_ranks([sys.executable, "-c", chatty], 2, out=out, err=err, timeout=60) == 0
+    assert time.time() - t0 < 30 and len(out.getvalue()) > 400000 and err.getvalue().count("e") >= 600000
+    t0 = time.time()
+    rc = MV.launch_local_ranks([sys.executable, "-c", "import time\ntime.sleep(60)\n"], 2, out=io.StringIO(),
+                               err=io.StringIO(), timeout=2)
+    assert rc == 124 and time.time() - t0 < 30
+
+
 def test_bench_refuses_a_rank_count_it_cannot_run():
     """python bench.py --gpus 2 on a host with fewer GPUs must fail loudly (never bench one GPU under n_gpus = 2)."""
     import subprocess
