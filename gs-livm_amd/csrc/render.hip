@@ -189,6 +189,26 @@ __device__ __forceinline__ uint32_t quad_hits(float x, float y, float hx, float 
 // those of a single launch over the concatenated list.
 constexpr uint32_t STOPPED_BIT = 0x80000000u;
 
+// Lane select by an explicit 64-bit lane mask held in scalar registers: bit set -> a, else b (one v_cndmask_b32).  The
+// forward blend keeps its per-pixel predicates (done, take, stop, ok) as such masks and combines them with a handful of
+// scalar ALU instructions; as loop-carried `bool`s the compiler turned every wave-wide test of them into a
+// v_cndmask 0/1 + v_cmp + s_cmp round trip and every `!x` of a float compare into a second compare.
+__device__ __forceinline__ float sel_f(uint64_t m, float a, float b) {
+  float d;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
+  return d;
+}
+__device__ __forceinline__ float sel_f0(uint64_t m, float a) {  // bit set -> a, else 0
+  float d;
+  asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(d) : "v"(a), "s"(m));
+  return d;
+}
+__device__ __forceinline__ uint32_t sel_u(uint64_t m, uint32_t a, uint32_t b) {
+  uint32_t d;
+  asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m));
+  return d;
+}
+
 template <int FW, int PHASE>  // FW quads (= waves) per workgroup: the waves never synchronise, FW only sets how many share a slot
 __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp, const uint2* __restrict__ ranges,
                                                       const uint2* __restrict__ rangesB,
@@ -217,9 +237,6 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
   // (wave-uniform by construction; made scalars by hand, see k_blend_backward_tile)
 #ifndef GSR_FWD_SCALAR
 #define GSR_FWD_SCALAR 0  // (scalarising the range / wave index by hand measured +3 %: more SALU on the walk's critical path)
-#endif
-#ifndef GSR_FWD_ONECMP
-#define GSR_FWD_ONECMP 1
 #endif
 #if GSR_FWD_SCALAR
 #define GSR_FWD_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
@@ -265,7 +282,9 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
     Dp = out_depth[pid];
     A = out_acc[pid];
   }
-  bool wave_done = __ballot(!done) == 0ull;
+  // (from here on the pixels' "done" flags live in one scalar lane mask)
+  uint64_t done_m = __builtin_amdgcn_ballot_w64(done);
+  bool wave_done = done_m == ~0ull;
 
   // software pipeline: (a, b, c, hit) hold the sub-chunk about to be consumed
   float4 a = make_float4(0, 0, 0, 0), b = a, c = a;
@@ -278,13 +297,23 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
     hit = splat_hits_quad(a, b, c, qx0, qy0);
   }
   for (int base = 0; base < n && !wave_done; base += 64) {
-    // published conic terms carry the constant factors of power = -1/2 (A dx^2 + C dy^2) - B dx dy and the
+    // The hits of the sub-chunk are published COMPACTED: hit number r (in list order: the rank of the lane among the
+    // hit lanes) goes to slot r of the wave's LDS image, together with the list position it stands for, so the walk below
+    // is a counted loop over slots 0 .. hits-1 with nothing but an address increment in the scalar unit.  Walking the
+    // set bits of the hit mask instead (s_ff1, a 64-bit mask clear, an address multiply per visit) cost 0.57 scalar
+    // instructions per vector instruction -- 50 M per frame at 2 M Gaussians / 1080p, two thirds of the one scalar
+    // unit a CU's 32 waves share.
+    // Published conic terms carry the constant factors of power = -1/2 (A dx^2 + C dy^2) - B dx dy and the
     // log2(e) of exp(x) = exp2(x log2 e): one multiply per ENTRY here instead of three per (entry, pixel) visit
     constexpr float L2E = 1.4426950408889634f;
-    sA[lane] = make_float4(a.x, a.y, a.z * (-0.5f * L2E), a.w * (-L2E));
-    sB[lane] = make_float4(b.x * (-0.5f * L2E), b.y, b.z, b.w);
-    sC[lane] = c;
-    uint64_t m = __ballot(hit);
+    const uint64_t m = __builtin_amdgcn_ballot_w64(hit);
+    const int nh = (int)__popcll(m);
+    if (hit) {
+      const uint32_t r = __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+      sA[r] = make_float4(a.x, a.y, a.z * (-0.5f * L2E), a.w * (-L2E));
+      sB[r] = make_float4(b.x * (-0.5f * L2E), b.y, b.z, b.w);
+      sC[r] = make_float4(c.x, c.y, __uint_as_float(pos0 + (uint32_t)(base + lane + 1)), 0.f);  // (.z: the list position)
+    }
     // issue the next sub-chunk's gather now; it completes while this one is blended
     const int jn = base + 64 + lane;
     hit = false;
@@ -297,66 +326,51 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
     }
     // Visit loop, software-pipelined by hand: the LDS broadcast reads of the NEXT hit are issued before the
     // current hit is blended (two register sets, no copies), so their latency hides behind ~30 VALU ops.
-    auto blend = [&](const float4 ra, const float4 rb, const float4 rc, const int jj) {
+    auto blend = [&](const float4 ra, const float4 rb, const float4 rc) {
       const float dx = ra.x - pfx, dy = ra.y - pfy;
       const float power = splat_power(ra.z, ra.w, rb.x, dx, dy);  // = log2(e) x the reference's power
       const float alpha = fminf(0.99f, rb.y * __builtin_amdgcn_exp2f(power));
-#if GSR_FWD_ONECMP
-      const bool take = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
+      // forward.cu:367-383: skip on power > 0 and alpha < 1/255; a pixel whose T would fall below 1e-4 stops BEFORE taking
+      // the splat.  Three compares straight into lane masks, the rest is scalar mask arithmetic.
+      const uint64_t take = __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
+                            __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f)) & ~done_m;
       const float test_T = T * (1.0f - alpha);
-      const bool low = test_T < 0.0001f;  // (one compare: `stop` and `ok` are both mask operations on it)
-      const bool stop = take && low;
-      done = done || stop;
-      const bool ok = take && !low;
-#else
-      bool ok = !done && !(power > 0.0f) && !(alpha < 1.0f / 255.0f);
-      const float test_T = T * (1.0f - alpha);
-      const bool stop = ok && (test_T < 0.0001f);
-      done = done || stop;
-      ok = ok && !stop;
-#endif
-      const float wgt = ok ? alpha * T : 0.0f;
+      const uint64_t low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+      done_m |= take & low;
+      const uint64_t ok = take & ~low;
+      const float wgt = sel_f0(ok, alpha * T);
       C0 += rb.z * wgt;
       C1 += rb.w * wgt;
       C2 += rc.x * wgt;
       Dp += rc.y * wgt;
       A += wgt;
-      T = ok ? test_T : T;
-      last = ok ? pos0 + (uint32_t)(base + jj + 1) : last;
+      T = sel_f(ok, test_T, T);
+      last = sel_u(ok, __float_as_uint(rc.z), last);
     };
-    if (m) {
-      int j0 = __builtin_ctzll(m), j1;
-      m &= m - 1;
-      float4 a0 = sA[j0], b0 = sB[j0], c0 = sC[j0], a1, b1, c1;
-      for (;;) {
-        j1 = -1;
-        if (m) {
-          j1 = __builtin_ctzll(m);
-          m &= m - 1;
-          a1 = sA[j1]; b1 = sB[j1]; c1 = sC[j1];
-        }
-        blend(a0, b0, c0, j0);
-        if (j1 < 0) {
-          wave_done = __ballot(!done) == 0ull;
+    if (nh) {
+      float4 a0 = sA[0], b0 = sB[0], c0 = sC[0], a1, b1, c1;
+      for (int r = 0;; r += 2) {
+        const bool has1 = r + 1 < nh;
+        if (has1) { a1 = sA[r + 1]; b1 = sB[r + 1]; c1 = sC[r + 1]; }
+        blend(a0, b0, c0);
+        if (!has1) {
+          wave_done = done_m == ~0ull;
           break;
         }
-        j0 = -1;
-        if (m) {
-          j0 = __builtin_ctzll(m);
-          m &= m - 1;
-          a0 = sA[j0]; b0 = sB[j0]; c0 = sC[j0];
-        }
-        blend(a1, b1, c1, j1);
-        wave_done = __ballot(!done) == 0ull;  // checked once per pair of visits: a visit after saturation changes nothing
-        if (wave_done || j0 < 0) break;
+        const bool has2 = r + 2 < nh;
+        if (has2) { a0 = sA[r + 2]; b0 = sB[r + 2]; c0 = sC[r + 2]; }
+        blend(a1, b1, c1);
+        wave_done = done_m == ~0ull;  // checked once per pair of visits: a visit after saturation changes nothing
+        if (wave_done || !has2) break;
       }
     }
   }
 
+  done = ((done_m >> lane) & 1ull) != 0ull;  // (back to a per-lane flag for the epilogue)
   const uint32_t wl = wave_max_u32(inside ? last : 0u);
   if (lane == 0) quad_last[quad] = wl;
   if (PHASE == 1) {
-    const bool all_stopped = __ballot(!done) == 0ull;
+    const bool all_stopped = done_m == ~0ull;
     if (lane == 0) {
       quad_done[quad] = all_stopped ? 1 : 0;
       const uint32_t old = atomicAdd(&s_done, 1u | (all_stopped ? 0u : 0x100u));

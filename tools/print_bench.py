@@ -2,15 +2,17 @@
 import json
 import sys
 
+items = []
 for path in sys.argv[1:]:
     try:
-        d = json.loads([l for l in open(path) if l.startswith("{")][-1])
-    except (OSError, IndexError, ValueError) as e:
+        lines = [l for l in open(path) if l.startswith("{")]
+        items += [("%s#%d" % (path, k) if len(lines) > 1 else path, json.loads(l)) for k, l in enumerate(lines)]
+    except (OSError, ValueError) as e:
         print(path, "unreadable:", e)
-        continue
+for path, d in items:
     sp = d.get("speculation") or {}
-    print("%s: ms/step %.4f  ms/view %.4f  value %.1f  | ovf %s skips %s misses %s async %s lost %s scale %s" % (
-        path, d["ms_per_step"], d.get("ms_per_view", d["ms_per_step"]), d["value"], sp.get("overflows"),
+    print("%s [%s]: ms/step %.4f  ms/view %.4f  value %.1f  | ovf %s skips %s misses %s async %s lost %s scale %s" % (
+        path, (d.get("config") or {}).get("workload", "")[:60], d["ms_per_step"], d.get("ms_per_view", d["ms_per_step"]), d["value"], sp.get("overflows"),
         sp.get("far_skips"), sp.get("far_skip_misses"), sp.get("async_far_frames"), sp.get("async_outcomes_lost"),
         sp.get("near_budget_scale_q8")))
     K = (d.get("config") or {}).get("views_per_gpu_per_step", 1) or 1
