@@ -148,10 +148,32 @@ uint32_t gsr_higher_msb(uint32_t n) {
   return msb;
 }
 
+// Blob sizes are rounded up to one sixteenth of their power of two (at most 6 % more, 1 MB at least): a map that grows by
+// a per cent every few iterations (gaussian.cu:241-313) then asks its allocator for the SAME size most of the time, and
+// a caching allocator (Torch's) can hand the previous blob back instead of going to the driver for a slightly larger
+// one -- every such trip is milliseconds, and the blocks it leaves behind fragment the pool.
+static size_t round_blob(size_t bytes) {
+  if (bytes < ((size_t)1 << 20)) return bytes;
+  size_t p2 = (size_t)1 << 20;
+  while ((p2 << 1) <= bytes) p2 <<= 1;
+  const size_t g = p2 >> 4 > ((size_t)1 << 20) ? p2 >> 4 : ((size_t)1 << 20);
+  return (bytes + g - 1) / g * g;
+}
+// (the same for a binning capacity predicted from history, in instances; capacities a caller or a test hook states
+// exactly are left alone)
+static uint32_t round_capacity(uint32_t n) {
+  if (n < (1u << 20)) return n;
+  uint32_t p2 = 1u << 20;
+  while (p2 <= (n >> 1)) p2 <<= 1;
+  const uint32_t g = p2 >> 4;
+  const unsigned long long r = ((unsigned long long)n + g - 1) / g * g;
+  return r > 0x7fffffffull ? 0x7fffffffu : (uint32_t)r;
+}
+
 size_t gsr_geometry_bytes(int P) {
   size_t b = 0;
   GeomState::carve(nullptr, (size_t)(P > 0 ? P : 0), &b);
-  return b;
+  return round_blob(b);
 }
 size_t gsr_image_bytes(int width, int height) {
   size_t b = 0;
@@ -847,7 +869,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
     c.hint_override = -1;
   } else {
     for (int k = 0; k < 4; k++) hint = h.recent[k] > hint ? h.recent[k] : hint;
-    if (hint) hint = (uint32_t)std::min<unsigned long long>(0x7fffffffull, (unsigned long long)hint * 5 / 4 + 65536);
+    if (hint)
+      hint = round_capacity((uint32_t)std::min<unsigned long long>(0x7fffffffull, (unsigned long long)hint * 5 / 4 + 65536));
   }
   const bool speculate = !debug && !env_sync && hint > 0;
   const std::chrono::steady_clock::time_point t_enq = std::chrono::steady_clock::now();
@@ -945,6 +968,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       } else if (h.have_far) {
         for (int k = 0; k < 4; k++) capB = h.recent_far[k] > capB ? h.recent_far[k] : capB;
         capB = (uint32_t)std::min<unsigned long long>(0x7fffffffull - capA, (unsigned long long)capB * 5 / 4 + 65536);
+        capB = std::min(round_capacity(capB), 0x7fffffffu - capA);
       } else {
         capB = hint > budget ? hint - budget : 0u;  // no history: room for every instance behind the budget
       }

@@ -331,7 +331,7 @@ hipError_t launch_emit_scatter(const EmitFusion& ef, uint16_t* keys_out, uint32_
 // scatters it stably and writes the ranges of its tiles: the second pass's histogram, scan and range launches are gone
 // (7 launches -> 4 per chain).  A bucket is one workgroup's serial job, so sorts beyond TILE_SORT_BUCKETS_MAX pairs
 // (one-chain frames of dense 1080p scenes) keep the two LSD passes, as do 32-bit keys and single-pass sorts.
-constexpr int TILE_SORT_BUCKETS_MAX = 16 << 20;
+constexpr int TILE_SORT_BUCKETS_MAX = 16 << 20;  // (measured at 1080p: 2.6 M pairs 24 vs 46 us for the LSD second pass; 27.7 M pairs 176 vs ~150)
 bool tile_sort_buckets(int tile_bits, bool key16, int capacity);
 struct BucketPass {
   uint2* ranges;        // the chain's tile ranges (written in full: (0, 0) for tiles without instances)
