@@ -134,6 +134,10 @@ def parse_args():
                          "views per optimiser iteration (the C4 yaw cameras in turn, advancing from step to step), their "
                          "losses summed, ONE backward, one Adam step.  value counts every rendered view's pixels; "
                          "ms_per_step is the whole iteration")
+    ap.add_argument("--view-threads", type=int, default=1,
+                    help="render the K views of an iteration from T host threads, each on a stream of its own (the "
+                         "reference renders from several threads, SURVEY.md 8b): one view's latency-bound binning chain "
+                         "then runs beside another view's blend kernels; the backwards follow on the same streams")
     ap.add_argument("--rotate-views", action="store_true",
                     help="K = 1: the camera still changes on every step (default: one fixed view, BASELINE C3)")
     ap.add_argument("--grow-every", type=int, default=0,
@@ -309,6 +313,10 @@ def main():
         else:
             opt = G.FusedAdam(groups, eps=1e-15)
         counter = {"step": 0, "grown": 0}
+        # --view-threads T: persistent rendering threads, each with a stream of its own and (inside the library) its own
+        # per-thread state; view j of an iteration always goes to thread j % T
+        T_views = max(1, min(args.view_threads, K))
+        workers = MV.ViewThreads(T_views, dev) if T_views > 1 else None
 
         def grow_model():
             """addNewPointcloud (gaussian.cu:241-313): --grow-points new Gaussians from the scene's own distribution."""
@@ -351,7 +359,11 @@ def main():
                     for j, rv in enumerate(views):
                         rv(xyz, sinks["t"][j], op, shs=shs, scales=sc, rotations=rot)
                 return
-            outs = [rv(xyz, sinks["t"][j], op, shs=shs, scales=sc, rotations=rot) for j, rv in enumerate(views)]
+            if workers is None:
+                outs = [rv(xyz, sinks["t"][j], op, shs=shs, scales=sc, rotations=rot) for j, rv in enumerate(views)]
+            else:
+                outs = workers.render([lambda rv=rv, j=j: rv(xyz, sinks["t"][j], op, shs=shs, scales=sc, rotations=rot)
+                                       for j, rv in enumerate(views)])
             for m2d in sinks["t"]:
                 m2d.grad = None
             if args.torch_optimizer and flat_grads:
@@ -425,6 +437,8 @@ def main():
                                      far_skips=b["far_skips"] - a["far_skips"],
                                      far_skip_misses=b["far_skip_misses"] - a["far_skip_misses"],
                                      near_budget_scale_q8=b["near_budget_scale_q8"], P=int(model._xyz.shape[0])))
+        if workers is not None:
+            workers.close()
         return dict(elapsed=elapsed, prof=prof, prof_timed=prof_timed, dom_name=dom_name, activated=activated,
                     tail=tail, broadcast_ms=broadcast_ms, speculation=speculation, per_step=per_step,
                     grown=counter["grown"], P_end=int(model._xyz.shape[0]), collective_bytes_per_step=(
@@ -551,6 +565,7 @@ def main():
                                 "forward only" if args.forward_only else
                                 ("fwd+bwd + Adam step" if K == 1 else "%d forwards, one backward, one Adam step" % K)),
                    "views_per_step": n_gpus * K, "views_per_gpu_per_step": K,
+                   "view_threads": max(1, min(args.view_threads, K)),
                    "camera": "the C4 yaw cameras in turn, a different one every forward" if rotate else "one fixed view",
                    "grow": (dict(every_steps=args.grow_every, points=args.grow_points, added=main_run["grown"],
                                  P_at_end=P) if args.grow_every else None),

@@ -344,8 +344,12 @@ PYBIND11_MODULE(TORCH_EXTENSION_NAME, m) {
            [opt](PyRasterizer& self, torch::Tensor means3D, torch::Tensor means2D, torch::Tensor opacities,
                  py::object shs, py::object colors_precomp, py::object scales, py::object rotations,
                  py::object cov3D_precomp) {
-             return self.impl.forward(means3D, means2D, opacities, opt(shs), opt(colors_precomp), opt(scales),
-                                      opt(rotations), opt(cov3D_precomp));
+             const torch::Tensor a = opt(shs), b = opt(colors_precomp), c = opt(scales), d = opt(rotations),
+                                 e = opt(cov3D_precomp);
+             // (no Python object is touched from here on: other rendering threads of the interpreter may run -- the
+             // reference's rendering threads are C++ threads and never meet a GIL)
+             py::gil_scoped_release unlocked;
+             return self.impl.forward(means3D, means2D, opacities, a, b, c, d, e);
            },
            py::arg("means3D"), py::arg("means2D"), py::arg("opacities"), py::arg("shs") = py::none(),
            py::arg("colors_precomp") = py::none(), py::arg("scales") = py::none(), py::arg("rotations") = py::none(),

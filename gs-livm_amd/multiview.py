@@ -171,3 +171,81 @@ def launch_local_ranks(argv, n_ranks, extra_env=None, timeout=3600.0, out=None, 
             if captured.get(("err", r)):
                 err.write(captured[("err", r)])
     return status
+
+
+class ViewThreads:
+    """The views of one optimiser iteration rendered from several host threads, each on a HIP stream of its own -- how
+    the reference drives the rasterizer (four rendering threads; one process, one GPU).  Views are
+    independent passes over the same Gaussians, and most of a forward is a chain of small latency-bound kernels (cull /
+    project, depth sort, offset scan, tile sort): issued from different streams, one view's chain runs beside another
+    view's blend kernels instead of in front of them (2 M Gaussians / 1080p, eight views per iteration: 1.01 -> 0.79 ms
+    per view with four threads).  The library keeps its per-thread state (mailbox, counters, per-view histories) per host
+    thread, so view j always goes to thread j % T and finds its own history there.
+
+        vt = ViewThreads(4, device)
+        outs = vt.render([lambda: rasterizer_j(means3D, means2D_j, opacity, shs=..., ...) for j in range(K)])
+        loss = sum(... outs ...); loss.backward()      # every backward runs on the stream its forward ran on
+
+    `render` makes each worker stream wait for the caller's current stream (the inputs are produced there), runs the
+    callables, and makes the caller's stream wait for the workers before it returns; results come back in call order.
+    """
+
+    def __init__(self, n_threads, device):
+        import queue
+        import threading
+
+        import torch
+        self._torch = torch
+        self.device = torch.device(device)
+        self._workers = []
+        for _ in range(max(1, int(n_threads))):
+            qi, qo = queue.Queue(), queue.Queue()
+            stream = torch.cuda.Stream(device=self.device)
+            th = threading.Thread(target=self._loop, args=(qi, qo, stream), daemon=True)
+            th.start()
+            self._workers.append((qi, qo, stream, th))
+
+    def _loop(self, qi, qo, stream):
+        torch = self._torch
+        torch.cuda.set_device(self.device)
+        while True:
+            job = qi.get()
+            if job is None:
+                return
+            try:
+                with torch.cuda.stream(stream):
+                    qo.put([fn() for fn in job])
+            except BaseException as e:  # noqa: BLE001 -- re-raised in the calling thread
+                qo.put(e)
+
+    def __len__(self):
+        return len(self._workers)
+
+    def render(self, calls):
+        torch = self._torch
+        calls = list(calls)
+        main = torch.cuda.current_stream(self.device)
+        T = len(self._workers)
+        jobs = [calls[w::T] for w in range(T)]
+        for (qi, qo, stream, th), job in zip(self._workers, jobs):
+            stream.wait_stream(main)
+            qi.put(job)
+        res, err = [], None
+        for qi, qo, stream, th in self._workers:
+            r = qo.get()
+            if isinstance(r, BaseException):
+                err = err or r
+                r = []
+            res.append(r)
+            main.wait_stream(stream)
+        if err is not None:
+            raise err
+        return [res[j % T][j // T] for j in range(len(calls))]
+
+    def close(self):
+        for qi, qo, stream, th in self._workers:
+            qi.put(None)
+        for qi, qo, stream, th in self._workers:
+            th.join(timeout=10.0)
+        self._workers = []
+

@@ -279,3 +279,18 @@ def test_exchange_steps_world_size_2_gloo():
     assert all(p.exitcode == 0 for p in ps)
     assert res[0][1] and res[1][1]
     assert res[0][2] == [0, 2, 4] and res[1][2] == [1, 3]
+
+
+def test_view_threads_keeps_call_order_and_reraises():
+    """gs_livm_amd.multiview.ViewThreads without a GPU kernel in sight: results come back in call order whatever thread
+    ran them, and an exception in a worker is re-raised in the calling thread."""
+    if not torch.cuda.is_available():
+        pytest.skip("ViewThreads creates HIP streams")
+    vt = MV.ViewThreads(3, "cuda:0")
+    try:
+        assert vt.render([lambda k=k: k * k for k in range(10)]) == [k * k for k in range(10)]
+        with pytest.raises(ZeroDivisionError):
+            vt.render([lambda: 1, lambda: 1 / 0, lambda: 3])
+        assert vt.render([lambda: "still alive"]) == ["still alive"]
+    finally:
+        vt.close()
