@@ -292,7 +292,7 @@ def main():
                 for name, key in (("_xyz", "means3D"), ("_features_dc", "features_dc"), ("_features_rest", "features_rest"),
                                   ("_scaling", "scales"), ("_rotation", "rotations"), ("_opacity", "opacities")):
                     getattr(model, name).copy_(v[key])
-            grow_rng = torch.Generator().manual_seed(seed + 77)
+            grow_rng = torch.Generator(device=dev).manual_seed(seed + 77)
         else:
             model = G.GaussianParameters(v["means3D"], v["features_dc"], v["features_rest"], v["scales"],
                                          v["rotations"], v["opacities"])
@@ -320,15 +320,16 @@ def main():
 
         def grow_model():
             """addNewPointcloud (gaussian.cu:241-313): --grow-points new Gaussians from the scene's own distribution."""
+            # (generated on the device: a burst of multi-threaded CPU work here can use up the container's CPU quota and
+            # get every host thread descheduled for the rest of the scheduler period -- see DESIGN.md, "mailbox")
             n = args.grow_points
-            z = 1.0 + 39.0 * torch.rand(n, generator=grow_rng)
+            r = lambda *shape: torch.rand(shape, generator=grow_rng, device=dev)  # noqa: E731
+            z = 1.0 + 39.0 * r(n)
             t = math.tan(math.radians(30.0))
-            xyz = torch.stack([(2 * torch.rand(n, generator=grow_rng) - 1) * 1.1 * z * t,
-                               (2 * torch.rand(n, generator=grow_rng) - 1) * 1.1 * z * t * H / W, z], 1)
-            sc2 = (0.004 + 0.056 * torch.rand((n, 3), generator=grow_rng)) ** 2
-            covs = torch.diag_embed(sc2)
-            rgbs = 255.0 * torch.rand((n, 3), generator=grow_rng)
-            model.add_new_pointcloud(xyz.to(dev), covs.to(dev), rgbs.to(dev), 1.0)
+            xyz = torch.stack([(2 * r(n) - 1) * 1.1 * z * t, (2 * r(n) - 1) * 1.1 * z * t * H / W, z], 1)
+            covs = torch.diag_embed((0.004 + 0.056 * r(n, 3)) ** 2)
+            rgbs = 255.0 * r(n, 3)
+            model.add_new_pointcloud(xyz, covs, rgbs, 1.0)
             sinks["P"] = model.P
             sinks["t"] = [torch.zeros((model.P, 3), device=dev, requires_grad=True) for _ in range(K)]
             counter["grown"] += n
@@ -428,12 +429,18 @@ def main():
             for _ in range(args.steps):
                 a = G.speculation_stats()
                 torch.cuda.synchronize()
+                ma = torch.cuda.memory_stats(dev)
                 ts = time.perf_counter()
                 step()
                 torch.cuda.synchronize()
                 ms = (time.perf_counter() - ts) * 1e3
                 b = G.speculation_stats()
+                mb = torch.cuda.memory_stats(dev)
                 per_step.append(dict(ms=round(ms, 4), overflows=b["overflows"] - a["overflows"],
+                                     # trips of the caching allocator to the driver during this step (a multi-GB blob: ~10 ms)
+                                     device_allocs=mb.get("num_device_alloc", 0) - ma.get("num_device_alloc", 0),
+                                     device_frees=mb.get("num_device_free", 0) - ma.get("num_device_free", 0),
+                                     slow_path=b["mailbox_slow_path_hits"] - a["mailbox_slow_path_hits"],
                                      far_skips=b["far_skips"] - a["far_skips"],
                                      far_skip_misses=b["far_skip_misses"] - a["far_skip_misses"],
                                      near_budget_scale_q8=b["near_budget_scale_q8"], P=int(model._xyz.shape[0])))

@@ -33,7 +33,8 @@ class ImageView(C.Structure):
 class MailboxEvent(C.Structure):
     _fields_ = [("count", C.c_uint), ("ticket_expected", C.c_uint32), ("ticket_seen_before_query", C.c_uint32),
                 ("elapsed_us", C.c_double), ("ticket_seen_after_query", C.c_uint32), ("first_query_result", C.c_int),
-                ("visible_at_query", C.c_int)]
+                ("visible_at_query", C.c_int), ("queries", C.c_uint), ("longest_query_us", C.c_double),
+                ("longest_poll_gap_us", C.c_double)]
 
 
 class NumRendered(int):

@@ -148,7 +148,7 @@ uint32_t gsr_higher_msb(uint32_t n) {
   return msb;
 }
 
-// Blob sizes are rounded up to one sixteenth of their power of two (at most 6 % more, 1 MB at least): a map that grows by
+// Blob sizes are rounded up to one eighth of their power of two (at most 12 % more, 1 MB at least): a map that grows by
 // a per cent every few iterations (gaussian.cu:241-313) then asks its allocator for the SAME size most of the time, and
 // a caching allocator (Torch's) can hand the previous blob back instead of going to the driver for a slightly larger
 // one -- every such trip is milliseconds, and the blocks it leaves behind fragment the pool.
@@ -156,7 +156,7 @@ static size_t round_blob(size_t bytes) {
   if (bytes < ((size_t)1 << 20)) return bytes;
   size_t p2 = (size_t)1 << 20;
   while ((p2 << 1) <= bytes) p2 <<= 1;
-  const size_t g = p2 >> 4 > ((size_t)1 << 20) ? p2 >> 4 : ((size_t)1 << 20);
+  const size_t g = p2 >> 3 > ((size_t)1 << 20) ? p2 >> 3 : ((size_t)1 << 20);
   return (bytes + g - 1) / g * g;
 }
 // (the same for a binning capacity predicted from history, in instances; capacities a caller or a test hook states
@@ -223,7 +223,7 @@ static std::atomic<unsigned long long> g_speculative_forwards{0}, g_speculation_
 // (the word appears some time after the stream has drained) from a late dispatch (the word is there as soon as a HIP
 // call has been made) the next time it occurs naturally.
 static std::mutex g_slow_mu;
-static gsr_mailbox_event g_slow_last = {0, 0, 0, 0.0, 0, 0, 0};
+static gsr_mailbox_event g_slow_last = {0, 0, 0, 0.0, 0, 0, 0, 0, 0.0, 0.0};
 
 // Per host thread and device: the mailbox, the kernel's "workgroups done" word, the two digit-histogram buffers and the
 // capacity prediction.  A host thread is inside gsr_forward for one forward at a time, and its forwards must be
@@ -259,6 +259,13 @@ struct ViewHist {
   uint32_t probe_scale_q8 = 256, probe_live = 0;
   int raise_cooldown = 0;                     // misses do not raise the budget while this runs (it did not help)
   bool near_list_too_long = false;            // the last partial depth sort's candidates were most of the scene
+  // High-water mark of the predicted binning capacity.  The prediction follows the instance count, which creeps up by a
+  // per cent whenever the map grows; asked for a slightly larger blob every few iterations, a caching allocator goes to
+  // the driver each time (a multi-GB binning blob: ~10 ms, four views: a 60 ms hiccup).  So a view keeps asking for the
+  // capacity it asked for last time until the prediction outgrows it, then jumps by a quarter; a prediction below half
+  // of it for 64 frames in a row lets it go.
+  uint32_t cap_hw = 0;
+  int cap_low_run = 0;
 };
 constexpr int VIEW_SLOTS = 32;
 
@@ -356,13 +363,23 @@ static int wait_num_rendered(ThreadCtx& c, hipStream_t stream, uint32_t* R_out, 
   const clk::time_point t0 = clk::now();
   const auto query_period = std::chrono::microseconds(25);
   clk::time_point next_query = t0 + std::chrono::microseconds(60);
+  // (how the wait is spent, for the slow path's record: see gsr_mailbox_event)
+  unsigned queries = 0;
+  double longest_query_us = 0.0, longest_gap_us = 0.0;
+  clk::time_point t_poll = t0;
   for (;;) {
     const unsigned long long v = __atomic_load_n(c.mailbox + word, __ATOMIC_ACQUIRE);
     if ((uint32_t)(v >> 32) == c.ticket) { *R_out = (uint32_t)v; return GSR_OK; }
     __builtin_ia32_pause();
-    if (clk::now() < next_query) continue;
+    const clk::time_point t_now = clk::now();
+    longest_gap_us = std::max(longest_gap_us, std::chrono::duration<double, std::micro>(t_now - t_poll).count());
+    t_poll = t_now;
+    if (t_now < next_query) continue;
     // slow path: notice a faulted or drained stream instead of spinning for ever
     const hipError_t q = hipStreamQuery(stream);
+    t_poll = clk::now();
+    longest_query_us = std::max(longest_query_us, std::chrono::duration<double, std::micro>(t_poll - t_now).count());
+    queries++;
     const unsigned long long v1 = __atomic_load_n(c.mailbox + word, __ATOMIC_ACQUIRE);
     if (q == hipSuccess) {  // everything enqueued has retired, so the word has been stored
       unsigned long long v2 = v1;
@@ -377,13 +394,17 @@ static int wait_num_rendered(ThreadCtx& c, hipStream_t stream, uint32_t* R_out, 
         g_slow_last.elapsed_us = std::chrono::duration<double, std::micro>(clk::now() - t0).count();
         g_slow_last.first_query_result = (int)q;
         g_slow_last.visible_at_query = (uint32_t)(v1 >> 32) == c.ticket;
+        g_slow_last.queries = queries;
+        g_slow_last.longest_query_us = longest_query_us;
+        g_slow_last.longest_poll_gap_us = longest_gap_us;
         g_slow_last.count = (unsigned)(g_mailbox_slow_hits.load() + 1);
       }
       const unsigned long long hits = ++g_mailbox_slow_hits;
       if (hits <= 3 || getenv("GSR_HOST_TRACE"))
         fprintf(stderr, "[gsr] mailbox slow path #%llu: ticket %u, seen %u before / %u right after hipStreamQuery (=%d), "
-                        "%.1f us after the enqueue: %s\n", hits, c.ticket, (uint32_t)(v >> 32), (uint32_t)(v1 >> 32), (int)q,
-                g_slow_last.elapsed_us, (uint32_t)(v1 >> 32) == c.ticket
+                        "%.1f us after the enqueue (%u queries, the longest took %.1f us; longest gap between two polls "
+                        "%.1f us): %s\n", hits, c.ticket, (uint32_t)(v >> 32), (uint32_t)(v1 >> 32), (int)q,
+                g_slow_last.elapsed_us, queries, longest_query_us, longest_gap_us, (uint32_t)(v1 >> 32) == c.ticket
                     ? "word present once a HIP call had been made (late dispatch / late visibility to the spinning load)"
                     : "word arrived after the stream had drained (store still in flight)");
       if ((uint32_t)(v2 >> 32) != c.ticket) {
@@ -863,14 +884,27 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
 
   static const bool env_sync = getenv("GSR_SYNC_FORWARD") != nullptr;
   static const bool host_trace = getenv("GSR_HOST_TRACE") != nullptr;  // diagnostics: host-side waits
-  uint32_t hint = 0;
+  uint32_t hint = 0, pred = 0;  // capacity to allocate for / instance count predicted (the decisions below use the latter)
   if (c.hint_override >= 0) {
-    hint = (uint32_t)c.hint_override;
+    hint = pred = (uint32_t)c.hint_override;
     c.hint_override = -1;
   } else {
     for (int k = 0; k < 4; k++) hint = h.recent[k] > hint ? h.recent[k] : hint;
-    if (hint)
+    if (hint) {
       hint = round_capacity((uint32_t)std::min<unsigned long long>(0x7fffffffull, (unsigned long long)hint * 5 / 4 + 65536));
+      pred = hint;
+      if (hint > h.cap_hw) {  // (ViewHist::cap_hw)
+        h.cap_hw = round_capacity((uint32_t)std::min<unsigned long long>(0x7fffffffull, (unsigned long long)hint * 5 / 4));
+        h.cap_low_run = 0;
+      } else if (hint < h.cap_hw / 2u) {
+        if (++h.cap_low_run >= 64) { h.cap_hw = hint; h.cap_low_run = 0; }
+      } else {
+        h.cap_low_run = 0;
+      }
+      hint = h.cap_hw;
+    } else {
+      h.cap_hw = 0;
+    }
   }
   const bool speculate = !debug && !env_sync && hint > 0;
   const std::chrono::steady_clock::time_point t_enq = std::chrono::steady_clock::now();
@@ -904,7 +938,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       getenv("GSR_NEAR_FAR_MIN_RATIO_Q2") ? strtoull(getenv("GSR_NEAR_FAR_MIN_RATIO_Q2"), nullptr, 10) : 12ull;
   const bool near_far = speculate && (t_near_far >= 0 ? t_near_far != 0 : near_far_flag().load() != 0) && !fp.ref_rects && near_entries > 0 &&
                         budget64 < 0x20000000ull && !split_paused &&
-                        (c.near_entries_override >= 0 || 4ull * (unsigned long long)hint >= env_ratio_q2 * budget64);  // (hook: always)
+                        (c.near_entries_override >= 0 || 4ull * (unsigned long long)pred >= env_ratio_q2 * budget64);  // (hook: always)
   // Far-chain speculation (see the near/far branch below): after two split frames in a row that left no quad
   // unfinished (or when the test hook asks) the thread's next split frame expects its far chain to stay idle.
   const bool speculate_far = near_far && (c.far_skip_override >= 0 ? c.far_skip_override == 1 : h.far_idle_streak >= 2);

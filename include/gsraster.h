@@ -364,6 +364,12 @@ typedef struct gsr_mailbox_event {
   uint32_t ticket_seen_after_query;
   int first_query_result;
   int visible_at_query;
+  /* how the wait was spent: stream queries made before the one that found the stream drained, the longest any single
+   * query took to RETURN, and the longest the host went without getting to run (gap between two polls of the word):
+   * a drained-late stream shows many quick queries, a stalled driver call one long query, a descheduled host thread one
+   * long gap */
+  unsigned queries;
+  double longest_query_us, longest_poll_gap_us;
 } gsr_mailbox_event;
 int gsr_mailbox_slow_path_last(gsr_mailbox_event* out);
 
