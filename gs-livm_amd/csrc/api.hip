@@ -304,10 +304,11 @@ struct ThreadCtx {
   // if so the far chain's instance count -- arrives in a mailbox slot of the frame's own (words 16 + 2 (seq & 7), + 1),
   // so a thread that runs several forwards ahead of the GPU still learns every outcome (lazy_resolve): up to eight
   // frames pending, oldest first.
-  struct Pending { uint32_t ticket, near, total; int w_live, w_far, view; unsigned gen; };
+  struct Pending { uint32_t ticket, near, total; int w_live, w_far, view; unsigned gen; bool speculated; };
   Pending pending[8];
   int pending_head = 0, pending_n = 0;
-  int w_live = 3, w_far = 1;                  // this forward's mailbox words for those two counts (3 / 1 unless asynchronous)
+  int w_live = 3, w_far = 1;                  // this forward's mailbox words for those two counts (3 / 1 unless lazy)
+  uint32_t lazy_seq = 0;                      // frames that returned before their far chain's outcome: slot = seq & 7
   const uint32_t* top_hist = nullptr;         // this forward's [count | tile sum] by top key byte (k_preprocess), or null
   ~ThreadCtx();                               // (a thread that ends gives the asynchronous mechanism back)
 };
@@ -664,8 +665,10 @@ static void lazy_resolve(ThreadCtx& c) {
     uint32_t live = 0, far = 0;
     if (!peek_word(c, p.w_live, p.ticket, &live)) return;
     if (live != 0u && !peek_word(c, p.w_far, p.ticket, &far)) return;
-    if (live == 0u) ++g_far_skips;
-    else ++g_far_skip_misses;
+    if (p.speculated) {  // (the speculation's own score: frames that enqueued their far chain outright are not counted)
+      if (live == 0u) ++g_far_skips;
+      else ++g_far_skip_misses;
+    }
     ViewHist& h = c.views[p.view];
     if (h.generation == p.gen) {  // (unless the slot has gone to another view meanwhile)
       budget_feedback(c, h, live, p.near, far, p.total);
@@ -676,14 +679,14 @@ static void lazy_resolve(ThreadCtx& c) {
     }
     if (p.ticket == c.ticket) {  // the thread's most recent forward: what gsr_last_* report
       c.last_far = far;
-      c.last_far_skipped = live == 0u;
+      c.last_far_skipped = p.speculated && live == 0u;
       c.last_R = c.last_near + c.last_far;
     }
     c.pending_head = (c.pending_head + 1) & 7;
     c.pending_n--;
   }
 }
-static void lazy_push(ThreadCtx& c, uint32_t ticket, uint32_t near, uint32_t total) {
+static void lazy_push(ThreadCtx& c, uint32_t ticket, uint32_t near, uint32_t total, bool speculated) {
   if (c.pending_n == 8) {  // nine frames in flight: the oldest one's slot is about to be reused -- its outcome is lost,
     ++g_async_outcomes_lost;  // which is taken for a miss (the speculation has to earn its streak again)
     const ThreadCtx::Pending& p = c.pending[c.pending_head];
@@ -692,7 +695,7 @@ static void lazy_push(ThreadCtx& c, uint32_t ticket, uint32_t near, uint32_t tot
     c.pending_n--;
   }
   c.pending[(c.pending_head + c.pending_n) & 7] =
-      ThreadCtx::Pending{ticket, near, total, c.w_live, c.w_far, c.cur, c.views[c.cur].generation};
+      ThreadCtx::Pending{ticket, near, total, c.w_live, c.w_far, c.cur, c.views[c.cur].generation, speculated};
   c.pending_n++;
 }
 
@@ -705,6 +708,7 @@ struct Chain {
   Count cnt;             // instances of this chain
   uint32_t near_budget;  // phase 1: the near phase ends with the Gaussian in whose slot run this falls
   uint32_t base;         // first slot / list position of this chain in the frame's slot space (phase 2: capA)
+  uint32_t expect = 0;   // instances this chain is expected to hold (0 = its capacity): picks the form of the tile sort
 };
 
 struct DepthOrder {
@@ -750,7 +754,10 @@ static int enqueue_chain(const FrameParams& fp, GeomState& g, ImageState& im, Bi
                               ch.phase == 1 ? dord.near_order : g.order, ch.phase == 1 && dord.partial, stream));
   // bucket form of the tile sort (gsr_internal.hpp): first pass on the top eight bits, then one launch per chain that
   // finishes every bucket and writes the ranges
-  const bool buckets = tile_sort_buckets(tile_bits, key16, cnt.cap);
+  // (a far chain's capacity may be every instance behind the near budget while it usually holds a few per cent of that:
+  // the form of the sort follows what is expected; either form is correct for any count)
+  const bool buckets = tile_sort_buckets(tile_bits, key16, ch.expect ? (int)std::min<uint32_t>(ch.expect, (uint32_t)cnt.cap)
+                                                                     : cnt.cap);
   const uint32_t shift0 = buckets ? (uint32_t)(tile_bits - 8) : 0u;
   const uint32_t mask0 = buckets ? 255u : (1u << sort_digit_bits(tile_bits)) - 1u;
   STAGE(launch_emit(fp, sdesc, cnt, chunk_first, start_in_A ? b.tkeysA : b.tkeysB, start_in_A ? point_list : b.ivalsB,
@@ -1020,7 +1027,12 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       // The near blend parks the unfinished pixels' state in the same way in every variant: same result.
       const bool async_far = speculate_far && async_far_ready(c);
       const bool skip_far = speculate_far && !async_far;
-      if (async_far && !capB_forced) capB = std::max(capB, hint > budget ? hint - budget : 0u);
+      // (Measured and not kept: frames that enqueue their far chain outright sizing the far segment like the asynchronous
+      // ones and returning without waiting for the far count.  Eight views per iteration from one thread: 0.985 -> 0.994 ms
+      // per view -- that loop is bound by the GPU, not by the host's wait -- at 1.9 GB of binning blob per view in flight.)
+      const bool lazy_cap = async_far && !capB_forced;
+      const uint32_t far_expect = std::max<uint32_t>(capB, 1u << 20);  // (from history, before the capacity is widened)
+      if (lazy_cap) capB = std::max(capB, hint > budget ? hint - budget : 0u);
       if (capB < 4096u) capB = 4096u;
       if ((unsigned long long)capA + capB > 0x7fffffffull) capB = 0x7fffffffu - capA;
       key = (int)(capA + capB);
@@ -1041,13 +1053,16 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
         aw.go = c.sig_go;
         aw.gate_dev = reinterpret_cast<uint32_t*>(c.done_counter + 2);
         aw.seq = ++c.async_seq;
-        c.w_live = 16 + 2 * (int)(aw.seq & 7u);  // this frame's own outcome slot (lazy_resolve)
+      }
+      if (lazy_cap) {
+        c.w_live = 16 + 2 * (int)(++c.lazy_seq & 7u);  // this frame's own outcome slot (lazy_resolve)
         c.w_far = c.w_live + 1;
       }
       int rc = enqueue_chain(fp, g, im, b, Chain{1, Count{g.total + 6, (int)capA}, budget, 0u}, c, dord, background, out_color,
                              out_depth, out_acc, debug, stream, aw);
       if (rc != GSR_OK) return rc;
-      Chain far_chain{2, Count{g.total + 8, (int)capB}, 0xFFFFFFFFu, capA};
+      Chain far_chain{2, Count{g.total + 8, (int)capB}, 0xFFFFFFFFu, capA, far_expect};
+      far_chain.cnt.bounded = lazy_cap;  // (a capacity that is rarely used: grid-stride over a bounded grid)
       uint32_t live = 0;
       c.last_far_skipped = false;
       if (async_far) {
@@ -1077,10 +1092,10 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       if ((rc = wait_num_rendered(c, stream, &R_host)) != GSR_OK) return rc;
       if ((rc = wait_num_rendered(c, stream, &R_near, 2)) != GSR_OK) return rc;
       bool know_far = true;
-      if (async_far && (unsigned long long)R_host - R_near <= (unsigned long long)capB) {
+      if (lazy_cap && (unsigned long long)R_host - R_near <= (unsigned long long)capB) {
         // the far segment holds whatever the far chain may emit: nothing left for the host to check or to wait for
         know_far = false;
-        lazy_push(c, c.ticket, R_near, R_host);
+        lazy_push(c, c.ticket, R_near, R_host, /*speculated=*/async_far);
         R_far = 0;
       } else {
         if ((rc = wait_num_rendered(c, stream, &live, c.w_live)) != GSR_OK) return rc;
@@ -1107,7 +1122,8 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
         fprintf(stderr, "[gsr] near/far forward: capacity %u + %u, near %u, far %u of %u instances, %u unfinished quads%s, "
                         "enqueue %.1f us, then waited %.1f us\n", capA, capB, R_near, R_far, R_host, live,
                 async_far ? (know_far ? " (asynchronous far chain, checked by the host)" : " (asynchronous far chain)")
-                : skip_far ? (live ? " (far chain enqueued late)" : " (far chain not enqueued)") : "",
+                : skip_far ? (live ? " (far chain enqueued late)" : " (far chain not enqueued)")
+                : "",
                 std::chrono::duration<double, std::micro>(tw - t_enq).count(),
                 std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - tw).count());
       ++g_speculative_forwards;

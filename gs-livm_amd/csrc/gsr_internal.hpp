@@ -249,6 +249,7 @@ struct Count {
   int cap;
   const uint32_t* gate = nullptr;
   uint32_t gate_open = 0;
+  bool bounded = false;  // grids of at most GATED_GRID_MAX workgroups although not gated (a capacity that is rarely used)
   // (the word is device memory and is read like the count below -- it was stored, write-through, before the stream
   // wait that precedes this kernel's launch was satisfied.  Tens of thousands of workgroups ask: an agent-scope atomic
   // load each serialises on the one address -- 0.14 ms for the 62 000 waves of an idle k_emit -- and a load from the
@@ -278,7 +279,7 @@ __host__ __device__ inline int units_of(int n, int per) { return (int)(((long lo
 // workgroups to launch for a chain's kernel whose work unit covers `per` instances
 inline int chain_grid(const Count& c, int per) {
   const int u = units_of(c.cap, per);
-  return c.gate && u > GATED_GRID_MAX ? GATED_GRID_MAX : u;
+  return (c.gate || c.bounded) && u > GATED_GRID_MAX ? GATED_GRID_MAX : u;
 }
 struct FrameParams {
   int P, D, M, W, H, gx, gy;
