@@ -209,6 +209,12 @@ __device__ __forceinline__ uint32_t sel_u(uint64_t m, uint32_t a, uint32_t b) {
   return d;
 }
 
+#ifndef GSR_FWD_ASM_VISIT
+#define GSR_FWD_ASM_VISIT 1
+#endif
+// slots of a wave's LDS image: 64 hits, +1 null entry padding an odd count, +1 read ahead by the walk
+constexpr int FWD_SLOTS = GSR_FWD_ASM_VISIT ? 66 : 64;
+
 template <int FW, int PHASE>  // FW quads (= waves) per workgroup: the waves never synchronise, FW only sets how many share a slot
 __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp, const uint2* __restrict__ ranges,
                                                       const uint2* __restrict__ rangesB,
@@ -224,7 +230,7 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
                                                       uint32_t* __restrict__ live_quads_out, const AsyncWords aw,
                                                       const Count gate) {
   if (PHASE == 2 && gate.closed()) return;  // (asynchronous frame whose near chain finished every quad)
-  __shared__ float4 sAll[FW][3][64];  // wave-private images: no barrier in the blending itself
+  __shared__ float4 sAll[FW][3][FWD_SLOTS];  // wave-private images: no barrier in the blending itself
   // PHASE 1 counts the quads it leaves unfinished and the launch's last workgroup hands the total to the host (api.hip:
   // a frame whose far chain was not enqueued is complete iff that total is zero).  Finished waves per workgroup and
   // their unfinished quads travel in one LDS word, finished workgroups and the running total in one 64-bit global word
@@ -235,6 +241,9 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
     __syncthreads();  // the only barrier: at the start, where no wave waits for a slower one
   }
   // (wave-uniform by construction; made scalars by hand, see k_blend_backward_tile)
+#ifndef GSR_FWD_EXEC_MASK
+#define GSR_FWD_EXEC_MASK 1
+#endif
 #ifndef GSR_FWD_SCALAR
 #define GSR_FWD_SCALAR 0  // (scalarising the range / wave index by hand measured +3 %: more SALU on the walk's critical path)
 #endif
@@ -338,6 +347,31 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
       const uint64_t low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
       done_m |= take & low;
       const uint64_t ok = take & ~low;
+#if GSR_FWD_EXEC_MASK
+      // The pixels that take the splat update their sums, T and last contributor under the execution mask `ok`: eight
+      // plain instructions.  (With selects -- weight or 0, new or old T, new or old position -- it is nine, three of
+      // them v_cndmask_b32 at 1.6 times the issue cost of a multiply-add: tools/valu_probe.hip.)  The compiler cannot
+      // be told to use a scalar lane mask as a branch condition without deriving a per-lane flag from it first, hence
+      // the assembly; the wave's execution mask is restored before anything else runs.
+      uint64_t exec_save;
+      float wgt;
+      asm volatile(
+          "s_and_saveexec_b64 %[sv], %[ok]\n\t"
+          "v_mul_f32_e32 %[w], %[al], %[T]\n\t"
+          "v_fmac_f32_e32 %[C0], %[cr], %[w]\n\t"
+          "v_fmac_f32_e32 %[C1], %[cg], %[w]\n\t"
+          "v_fmac_f32_e32 %[C2], %[cb], %[w]\n\t"
+          "v_fmac_f32_e32 %[Dp], %[dz], %[w]\n\t"
+          "v_add_f32_e32 %[A], %[A], %[w]\n\t"
+          "v_mov_b32_e32 %[T], %[tT]\n\t"
+          "v_mov_b32_e32 %[last], %[pos]\n\t"
+          "s_mov_b64 exec, %[sv]"
+          : [sv] "=&s"(exec_save), [w] "=&v"(wgt), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [Dp] "+v"(Dp), [A] "+v"(A),
+            [T] "+v"(T), [last] "+v"(last)
+          : [ok] "s"(ok), [al] "v"(alpha), [cr] "v"(rb.z), [cg] "v"(rb.w), [cb] "v"(rc.x), [dz] "v"(rc.y), [tT] "v"(test_T),
+            [pos] "v"(rc.z)
+          : "scc");
+#else
       const float wgt = sel_f0(ok, alpha * T);
       C0 += rb.z * wgt;
       C1 += rb.w * wgt;
@@ -346,7 +380,84 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
       A += wgt;
       T = sel_f(ok, test_T, T);
       last = sel_u(ok, __float_as_uint(rc.z), last);
+#endif
     };
+#if GSR_FWD_ASM_VISIT
+    // One visit = one block of assembly: 23 vector and 4 scalar instructions.  The skip / stop rules of forward.cu:367-383
+    // narrow the execution mask step by step -- not-yet-stopped pixels (s_andn1_saveexec), power <= 0 and alpha >= 1/255
+    // (two v_cmpx), then T (1 - alpha) >= 1e-4 (the pixels that fail it are added to the `done` mask and leave) -- and the
+    // pixels still active take the splat.  As C++ the same rules cost 13 scalar instructions per visit (lane masks
+    // combined with s_and / s_or / s_andn2, loop flags through s_cselect and vcc branches): 43 M per frame at 2 M Gaussians /
+    // 1080p on the ONE scalar unit the CU's waves share, which was as busy as the vector units (profiles/r03e_sq_probe.txt).
+    // Same arithmetic, same order of roundings as `blend` above: images and n_contrib are bit-identical.
+    auto visit = [&](const float4 ra, const float4 rb, const float4 rc) {
+      float t0, t1, dx, dy;
+      uint64_t sv;
+      asm volatile(
+          "v_sub_f32_e32 %[dx], %[ax], %[pfx]\n\t"
+          "v_sub_f32_e32 %[dy], %[ay], %[pfy]\n\t"
+          "v_mul_f32_e32 %[t0], %[dx], %[dx]\n\t"
+          "v_mul_f32_e32 %[t1], %[Cc], %[dy]\n\t"
+          "v_mul_f32_e32 %[t0], %[Aa], %[t0]\n\t"
+          "v_fmac_f32_e32 %[t1], %[Bb], %[dx]\n\t"
+          "v_fmac_f32_e32 %[t0], %[t1], %[dy]\n\t"      // power (x log2 e)
+          "v_exp_f32_e32 %[t1], %[t0]\n\t"
+          // (gfx950 does not interlock a transcendental's result against the very next vector instruction -- the
+          // compiler keeps one instruction between them, and so must hand-written code: the first narrowing goes here)
+          "s_andn1_saveexec_b64 %[sv], %[done]\n\t"     // pixels that have not stopped
+          "v_cmpx_nlt_f32_e32 vcc, 0, %[t0]\n\t"        // ... with !(power > 0)
+          "v_mul_f32_e32 %[t1], %[op], %[t1]\n\t"
+          "v_min_f32_e32 %[t1], 0x3f7d70a4, %[t1]\n\t"  // alpha = min(0.99, opacity G)
+          "v_sub_f32_e32 %[dx], 1.0, %[t1]\n\t"
+          "v_mul_f32_e32 %[dx], %[T], %[dx]\n\t"        // test_T = T (1 - alpha)
+          "v_cmpx_ngt_f32_e32 vcc, 0x3b808081, %[t1]\n\t"  // ... and !(alpha < 1/255)
+          "v_cmp_gt_f32_e32 vcc, 0x38d1b717, %[dx]\n\t"    // of those: test_T < 1e-4 -> the pixel stops BEFORE this splat
+          "s_or_b64 %[done], %[done], vcc\n\t"
+          "s_andn2_b64 exec, exec, vcc\n\t"
+          "v_mul_f32_e32 %[t0], %[t1], %[T]\n\t"        // weight = alpha T
+          "v_fmac_f32_e32 %[C0], %[cr], %[t0]\n\t"
+          "v_fmac_f32_e32 %[C1], %[cg], %[t0]\n\t"
+          "v_fmac_f32_e32 %[C2], %[cb], %[t0]\n\t"
+          "v_fmac_f32_e32 %[Dp], %[dz], %[t0]\n\t"
+          "v_add_f32_e32 %[A], %[A], %[t0]\n\t"
+          "v_mov_b32_e32 %[T], %[dx]\n\t"
+          "v_mov_b32_e32 %[last], %[pos]\n\t"
+          "s_mov_b64 exec, %[sv]"
+          : [t0] "=&v"(t0), [t1] "=&v"(t1), [dx] "=&v"(dx), [dy] "=&v"(dy), [sv] "=&s"(sv), [done] "+s"(done_m),
+            [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [Dp] "+v"(Dp), [A] "+v"(A), [T] "+v"(T), [last] "+v"(last)
+          : [ax] "v"(ra.x), [ay] "v"(ra.y), [Aa] "v"(ra.z), [Bb] "v"(ra.w), [Cc] "v"(rb.x), [op] "v"(rb.y), [cr] "v"(rb.z),
+            [cg] "v"(rb.w), [cb] "v"(rc.x), [dz] "v"(rc.y), [pos] "v"(rc.z), [pfx] "v"(pfx), [pfy] "v"(pfy)
+          : "vcc", "scc");
+    };
+    if (nh) {
+      // (an odd count is padded with a null entry -- opacity 0, so alpha = 0 and no pixel takes it: the walk below goes
+      // in pairs without a test in the middle, and reads one slot ahead, hence FWD_SLOTS)
+      if (lane == 0 && (nh & 1)) {
+        sA[nh] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sB[nh] = make_float4(0.f, 0.f, 0.f, 0.f);
+        sC[nh] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      const int nh2 = (nh + 1) & ~1;
+      float4 a0 = sA[0], b0 = sB[0], c0 = sC[0];
+      // Each entry is read from LDS one visit before it is used, and waited for right after the visit that covered its
+      // latency (s_waitcnt lgkmcnt(0) only: the next chunk's global gathers stay in flight).  Left to itself the
+      // compiler waits at the first use, behind the younger reads of the other register set: one exposed LDS round
+      // trip per pair of visits.
+      __builtin_amdgcn_s_waitcnt(0xC07F);
+      for (int r = 0; r < nh2; r += 2) {
+        const float4 a1 = sA[r + 1], b1 = sB[r + 1], c1 = sC[r + 1];
+        visit(a0, b0, c0);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        a0 = sA[r + 2]; b0 = sB[r + 2]; c0 = sC[r + 2];  // (slot nh2 <= 64: read, never used)
+        visit(a1, b1, c1);
+        __builtin_amdgcn_s_waitcnt(0xC07F);
+        if (done_m == ~0ull) {  // checked once per pair of visits: a visit after saturation changes nothing
+          wave_done = true;
+          break;
+        }
+      }
+    }
+#else
     if (nh) {
       float4 a0 = sA[0], b0 = sB[0], c0 = sC[0], a1, b1, c1;
       for (int r = 0;; r += 2) {
@@ -364,6 +475,7 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
         if (wave_done || !has2) break;
       }
     }
+#endif
   }
 
   done = ((done_m >> lane) & 1ull) != 0ull;  // (back to a per-lane flag for the epilogue)
@@ -690,6 +802,9 @@ __global__ __launch_bounds__(1024) void k_tile_order(const uint32_t* __restrict_
 #ifndef GSR_BWD_MIN_WAVES
 #define GSR_BWD_MIN_WAVES 1
 #endif
+#ifndef GSR_BWD_EXEC_MASK
+#define GSR_BWD_EXEC_MASK 1
+#endif
 template <int TW>  // tiles (= waves) per workgroup; the waves never synchronise
 __global__ __launch_bounds__(64 * TW, GSR_BWD_MIN_WAVES) void k_blend_backward_tile(
     const FrameParams fp, const uint2* __restrict__ ranges, const uint32_t* __restrict__ quad_last_in,
@@ -787,7 +902,11 @@ __global__ __launch_bounds__(64 * TW, GSR_BWD_MIN_WAVES) void k_blend_backward_t
       // lane-local sums over the lane's four pixels: colour (3), dLG, dLG dy, dLG dy^2 (accumulated as fused
       // multiply-adds: combining the four pixels costs no instruction of its own)
       float c0 = 0.f, c1 = 0.f, c2 = 0.f, sG = 0.f, sGy = 0.f, sGyy = 0.f;
+#if GSR_BWD_EXEC_MASK
+      uint64_t anym = 0ull;  // lanes one of whose four pixels takes the splat
+#else
       uint32_t abits = 0u;  // OR of the lane's four alphas: non-zero iff one of its pixels takes the splat
+#endif
 #pragma unroll
       for (int k = 0; k < 4; k++) {
         const float dy = ea.y - pfy[k];
@@ -795,6 +914,37 @@ __global__ __launch_bounds__(64 * TW, GSR_BWD_MIN_WAVES) void k_blend_backward_t
         const float Graw = __builtin_amdgcn_exp2f(power);
         const float araw = fminf(0.99f, eb.y * Graw);
         const bool ok = (pos < lastc[k]) && !(power > 0.0f) && !(araw < 1.0f / 255.0f);
+#if GSR_BWD_EXEC_MASK
+        // The pixels that take this splat run the update under the execution mask; the others keep their recurrence
+        // state and add nothing -- no select instructions (a v_cndmask / v_cmp / v_min costs 1.6 plain multiply-adds on
+        // this chip, tools/valu_probe.hip), and a strip no pixel of which takes the splat costs the test only.
+        // (a ballot of the conjunction would be materialised as a select and a compare: and the three masks instead)
+        anym |= __builtin_amdgcn_ballot_w64(pos < lastc[k]) & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
+                __builtin_amdgcn_ballot_w64(!(araw < 1.0f / 255.0f));
+        {
+          if (ok) {
+            const float rom = __builtin_amdgcn_rcpf(1.0f - araw);
+            const float Tn = T[k] * rom;  // T / (1 - alpha)
+            const float D =
+                __builtin_fmaf(eb.z, dp0[k], __builtin_fmaf(eb.w, dp1[k], __builtin_fmaf(blue, dp2[k], dacc[k]))) - S[k];
+            const float dch = araw * Tn;
+            const float dL_dalpha = Tn * D;
+            const float dLG = Graw * dL_dalpha;  // dL/dG up to the opacity factor; also the opacity partial itself
+            const float sy = dLG * dy;
+            c0 = __builtin_fmaf(dch, dp0[k], c0);
+            c1 = __builtin_fmaf(dch, dp1[k], c1);
+            c2 = __builtin_fmaf(dch, dp2[k], c2);
+            sG += dLG;
+            sGy += sy;
+            sGyy = __builtin_fmaf(sy, dy, sGyy);
+            // Fold this splat into the "everything behind the next one" accumulators (the reference does it at the top
+            // of its next iteration from saved (last_alpha, last_color), backward.cu:533-543): accum + alpha (c - accum)
+            T[k] = Tn;
+            S[k] = __builtin_fmaf(araw, D, S[k]);
+          }
+        }
+      }
+#else
         // Branch-free per lane: a pixel that does not take this splat runs with alpha = 0 and G = 0 -- exact zero
         // partials, recurrence state untouched bit for bit (see k_blend_backward)
         const float alpha = ok ? araw : 0.0f;
@@ -822,7 +972,9 @@ __global__ __launch_bounds__(64 * TW, GSR_BWD_MIN_WAVES) void k_blend_backward_t
         T[k] = Tn;
         S[k] = __builtin_fmaf(alpha, D, S[k]);
       }
-      if (__ballot(abits != 0u) != 0ull) {
+      const uint64_t anym = __ballot(abits != 0u);
+#endif
+      if (anym != 0ull) {
         // the lane's pixels share dx: sum dLG dx = dx sum dLG, sum dLG dx^2 = dx^2 sum dLG, sum dLG dx dy = dx sum dLG dy
         float v0 = c0, v1 = c1, v2 = c2, v3 = dx * sG, v4 = sGy, v5 = dx2 * sG, v6 = dx * sGy, v7 = sGyy, g8 = sG;
         swap_add32(v0, v4);
