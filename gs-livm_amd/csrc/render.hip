@@ -350,7 +350,7 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
 #if GSR_FWD_EXEC_MASK
       // The pixels that take the splat update their sums, T and last contributor under the execution mask `ok`: eight
       // plain instructions.  (With selects -- weight or 0, new or old T, new or old position -- it is nine, three of
-      // them v_cndmask_b32 at 1.6 times the issue cost of a multiply-add: tools/valu_probe.hip.)  The compiler cannot
+      // them v_cndmask_b32 at 1.6 times the issue cost of a multiply-add: tools/microbench/valu_probe.hip.)  The compiler cannot
       // be told to use a scalar lane mask as a branch condition without deriving a per-lane flag from it first, hence
       // the assembly; the wave's execution mask is restored before anything else runs.
       uint64_t exec_save;
@@ -917,7 +917,7 @@ __global__ __launch_bounds__(64 * TW, GSR_BWD_MIN_WAVES) void k_blend_backward_t
 #if GSR_BWD_EXEC_MASK
         // The pixels that take this splat run the update under the execution mask; the others keep their recurrence
         // state and add nothing -- no select instructions (a v_cndmask / v_cmp / v_min costs 1.6 plain multiply-adds on
-        // this chip, tools/valu_probe.hip), and a strip no pixel of which takes the splat costs the test only.
+        // this chip, tools/microbench/valu_probe.hip), and a strip no pixel of which takes the splat costs the test only.
         // (a ballot of the conjunction would be materialised as a select and a compare: and the three masks instead)
         anym |= __builtin_amdgcn_ballot_w64(pos < lastc[k]) & __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
                 __builtin_amdgcn_ballot_w64(!(araw < 1.0f / 255.0f));

@@ -1,5 +1,5 @@
 // valu_probe.hip -- what does one VALU instruction cost on this chip, per SIMD, at 1..8 waves per SIMD?
-//   hipcc --offload-arch=gfx950 -O2 tools/valu_probe.hip -o gpurun_out/valu_probe && gpurun_out/valu_probe
+//   hipcc --offload-arch=gfx950 -O2 tools/microbench/valu_probe.hip -o gpurun_out/valu_probe && gpurun_out/valu_probe
 // Every wave runs ITER x 64 instructions of one kind on eight independent accumulators; the grid is 256 CUs x W
 // workgroups of 256 threads (one wave per SIMD each).  Reported: cycles per wave-instruction per SIMD, from the shader
 // clock (s_memtime) and from hipEvents at an assumed 2.4 GHz.  A measurement tool: nothing in the product uses it.
