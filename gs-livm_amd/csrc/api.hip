@@ -325,7 +325,7 @@ static int ctx_prepare(ThreadCtx& c, hipStream_t stream) {
         hipHostGetDevicePointer(&d, h, 0) != hipSuccess || hipMalloc(&k, 64 + 2 * 5120) != hipSuccess ||
         hipMemset(k, 0, 64 + 2 * 5120) != hipSuccess)
       return fail(GSR_ERR_HIP, "cannot allocate the host-mapped mailbox: %s", hipGetErrorString(hipGetLastError()));
-    c.mailbox = static_cast<unsigned long long*>(h);  // (a previous device's 128 bytes stay allocated: switching is rare)
+    c.mailbox = static_cast<unsigned long long*>(h);  // (a previous device's 256 bytes stay allocated: switching is rare)
     c.mailbox_dev = static_cast<unsigned long long*>(d);
     c.done_counter = static_cast<unsigned long long*>(k);
     c.device = cur_device;
@@ -336,7 +336,7 @@ static int ctx_prepare(ThreadCtx& c, hipStream_t stream) {
     c.pending_n = 0;
     // word 0: num_rendered; near/far frames: 1 = far count, 2 = near count, 3 = unfinished quads, 4 = near candidates;
     // 16 .. 31: (unfinished quads, far count) of asynchronous frame seq in slot seq & 7
-    for (int k = 0; k < MAILBOX_WORDS; k++) c.mailbox[k] = 0;
+    for (int w = 0; w < MAILBOX_WORDS; w++) c.mailbox[w] = 0;
     (void)hipDeviceSynchronize();  // the counter is zero before any stream uses it
   }
   if (c.used && stream != c.last_stream) {
@@ -487,6 +487,13 @@ ThreadCtx::~ThreadCtx() {
   sig_decide = sig_go = nullptr;
   const void* me = this;
   (void)g_async_owner.compare_exchange_strong(me, nullptr);
+  // the thread's mailbox and counter words (hipFree waits for the device: kernels of this thread's last frames may
+  // still be counting into them)
+  if (done_counter) (void)hipFree(done_counter);
+  if (mailbox) (void)hipHostFree(mailbox);
+  done_counter = nullptr;
+  mailbox = mailbox_dev = nullptr;
+  (void)hipGetLastError();
 }
 
 static bool async_far_ready(ThreadCtx& c) {
