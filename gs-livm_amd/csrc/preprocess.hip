@@ -1306,82 +1306,174 @@ __device__ __forceinline__ void swap_add16_(float& a, float& b) {
   a = __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
-__global__ __launch_bounds__(PRE_BLOCK) void k_gather_records(
+// (the register allocator settles on 102 VGPRs = four waves per SIMD for k_gather_records; asked for 96 it finds 86 without a spill)
+#ifndef GSR_GATHER_ATTR
+#define GSR_GATHER_ATTR __attribute__((amdgpu_num_vgpr(96)))
+#endif
+// the nine sums of one Gaussian's records, per lane (lane = slot mod 64)
+struct RecordSums {
+  float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0;
+};
+// Slots [base, base + 512) of the run [first, first + n): the eight flags of a lane are requested at once, then its
+// flagged records in two groups of four, summed in slot order (three round trips for 512 slots; 1024 slots at a time
+// with sixteen flags measured slower: registers).
+constexpr uint32_t GATHER_CHUNK = 512;
+constexpr uint32_t GATHER_SHARED_FROM = 2048;  // runs longer than this are shared by the workgroup's waves
+__device__ __forceinline__ void gather_chunk(const size_t first, const uint32_t n, const uint32_t base, const int lane,
+                                             const float4* __restrict__ grad_inst, uint8_t* __restrict__ inst_flag,
+                                             RecordSums& r) {
+  uint8_t f[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) {
+    const uint32_t k = base + 64 * j + lane;
+    f[j] = k < n ? inst_flag[first + k] : (uint8_t)0;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) {
+    if (base + 256u * q >= n) break;  // (wave-uniform)
+    float4 a[4], b[4], c[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (f[4 * q + j]) {
+        const size_t slot = first + base + 64 * (4 * q + j) + lane;
+        inst_flag[slot] = 0;  // consumed: the blobs are clean for another backward
+        a[j] = grad_inst[slot * GRAD_F4 + 0];
+        b[j] = grad_inst[slot * GRAD_F4 + 1];
+        c[j] = grad_inst[slot * GRAD_F4 + 2];
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      if (f[4 * q + j]) {
+        r.v0 += a[j].x; r.v1 += a[j].y; r.v2 += a[j].z; r.v3 += a[j].w;
+        r.v4 += b[j].x; r.v5 += b[j].y; r.v6 += b[j].z; r.v7 += b[j].w;
+        r.v8 += (c[j].x + c[j].y) + (c[j].z + c[j].w);  // the four 16-lane-row sums of dLG the tile kernel leaves
+      }
+    }
+  }
+}
+// Wave reduction of the per-lane sums and the Gaussian's four gradient rows.  The records hold RAW pixel sums (colour
+// r g b | S3 = sum dLG dx, S4 = sum dLG dy | S5 = sum dLG dx^2, S6 = sum dLG dx dy, S7 = sum dLG dy^2 | sum dLG),
+// dLG = G dL/dalpha.  The factors every pixel and every instance of the Gaussian share are applied here, ONCE per
+// Gaussian (backward.cu:561-562, 583-597):
+//   dL/dmean2D = -(conic (S3, S4)) * opacity * (W/2, H/2),  dL/dconic = -1/2 opacity (S5, S6, S7),  dL/dopacity = sum dLG
+__device__ __forceinline__ void gather_finish(RecordSums r, const uint32_t id, const int lane, const float cx, const float cy,
+                                              const float cz, const float op, const float ddelx_dx, const float ddely_dy,
+                                              float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic,
+                                              float* __restrict__ dL_dopacity, float* __restrict__ dL_dcolor) {
+  // (v0,v4) (v1,v5) (v2,v6) (v3,v7) across half-waves, then rows, then inside rows
+  swap_add32_(r.v0, r.v4);
+  swap_add32_(r.v1, r.v5);
+  swap_add32_(r.v2, r.v6);
+  swap_add32_(r.v3, r.v7);
+  swap_add16_(r.v0, r.v2);  // rows hold v0, v2, v4, v6
+  swap_add16_(r.v1, r.v3);  // rows hold v1, v3, v5, v7
+  const float w0 = row_allsum_(r.v0), w1 = row_allsum_(r.v1);
+  float v8 = row_allsum_(r.v8);
+  v8 += dpp_get_<0x142, 0xA>(v8);  // row_bcast:15
+  v8 += dpp_get_<0x143, 0xC>(v8);  // row_bcast:31 -> total in lane 63
+  const float S3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), 16));
+  const float S4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0), 32));
+  const float mc = -0.5f * op;
+  if (lane == 0) { dL_dcolor[3 * id] = w0; dL_dcolor[3 * id + 1] = w1; }
+  if (lane == 16) { dL_dcolor[3 * id + 2] = w0; dL_dmean2D[3 * id] = -(cx * S3 + cy * S4) * (op * ddelx_dx); }
+  if (lane == 32) { dL_dmean2D[3 * id + 1] = -(cz * S4 + cy * S3) * (op * ddely_dy); dL_dconic[4 * id] = w1 * mc; }
+  if (lane == 48) { dL_dconic[4 * id + 1] = w0 * mc; dL_dconic[4 * id + 3] = w1 * mc; }
+  if (lane == 63) dL_dopacity[id] = v8;
+}
+
+__global__ __launch_bounds__(PRE_BLOCK) GSR_GATHER_ATTR void k_gather_records(
     GeomState g, const float4* __restrict__ grad_inst, uint8_t* __restrict__ inst_flag,
     float* __restrict__ dL_dmean2D, float* __restrict__ dL_dconic, float* __restrict__ dL_dopacity,
     float* __restrict__ dL_dcolor, const float ddelx_dx, const float ddely_dy, const int P, const bool from_descriptors) {
-  const int lane = threadIdx.x & 63;
-  const uint32_t nwaves = gridDim.x * (PRE_BLOCK / 64);
-  const uint32_t wid = blockIdx.x * (PRE_BLOCK / 64) + (threadIdx.x >> 6);
+  constexpr int NW = PRE_BLOCK / 64;
+  __shared__ uint32_t s_long[PRE_BLOCK];  // Gaussians of this round whose runs the workgroup's waves share
+  __shared__ uint32_t s_nlong;
+  __shared__ float s_part[NW][9][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const uint32_t nwaves = gridDim.x * NW;
   // Which Gaussians have records: the list k_compact_touched made of the flagged ones -- or, in a near/far frame, simply
   // the Gaussians the frame emitted (a few per cent of the scene: the near chain's descriptors [0, total[7]) and the far
   // chain's [0, total[10])), each asked for its flag: no compaction launch over all P flags
   const uint32_t nA = from_descriptors ? g.total[7] : 0u;
   const uint32_t count = from_descriptors ? nA + g.total[10] : g.total[2];
-  // A wave examines 64 candidates per round -- lane l the one at position (round * 64 + l) * nwaves + wid, so the
-  // Gaussians with the longest runs, which sit next to each other at the front of the near chain, still go to
-  // different waves -- and gathers those that have records one after the other.  From the touched list every candidate
-  // has records; from the descriptors of a near/far frame whose far chain ran most do not (far Gaussians are emitted
-  // with their whole rectangle as soon as ONE tile of it is live): asked one per wave iteration, the two dependent loads
-  // of each rejected candidate cost a round trip of their own (0.09 instead of 0.04 ms at 2 M Gaussians / 1080p).
+  // A wave examines 64 candidates per round -- consecutive candidates go to different WORKGROUPS first, then to the
+  // workgroups' other waves, then to the waves' other lanes: the Gaussians with the longest runs sit next to each other
+  // at the front of the near chain -- and gathers those that have records one after the other.  From the touched list
+  // every candidate has records; from the descriptors of a near/far frame whose far chain ran most do not (far Gaussians
+  // are emitted with their whole rectangle as soon as ONE tile of it is live): asked one per wave iteration, the two
+  // dependent loads of each rejected candidate cost a round trip of their own (0.09 instead of 0.04 ms at 2 M Gaussians /
+  // 1080p).
+  // A run of up to 2048 slots is one wave's job (512 slots at a time: flags, then the flagged records).  LONGER
+  // runs -- a Gaussian that comes close to the camera plane of a turned view covers the whole image, 8160 slots at
+  // 1080p: a few dozen of those, walked serially by the waves they fell to, WERE the kernel (80 us,
+  // tools/gather_stats.py) -- go on the workgroup's list and are shared by its four waves, 512-slot chunks in turn, the
+  // waves' per-lane sums added in wave order: a fixed association order for every Gaussian, so the backward stays
+  // bitwise reproducible.  (count is the same in every wave: the barriers below are reached by all of them.)
   for (uint32_t base = 0; base < count; base += 64u * nwaves) {
-  const uint32_t qc = base + (uint32_t)lane * nwaves + wid;
-  uint32_t cand = 0xFFFFFFFFu;
-  if (qc < count) cand = !from_descriptors ? g.tlist[qc] : qc < nA ? g.sdesc[qc].y : g.sdescB[qc - nA].y;
-  // (emitted, but no pixel took it: no record)
-  const bool has = cand < (uint32_t)P && (!from_descriptors || g.touched[cand] != 0);
-  for (uint64_t todo = __ballot(has); todo != 0ull; todo &= todo - 1ull) {
-    const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)cand, __builtin_ctzll(todo));
-    const size_t first = g.slotinfo[id].x;
-    const uint32_t n = g.gpack[id].x;
-    float v0 = 0, v1 = 0, v2 = 0, v3 = 0, v4 = 0, v5 = 0, v6 = 0, v7 = 0, v8 = 0;
-    for (uint32_t base = 0; base < n; base += 256) {
-      uint8_t f[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        const uint32_t k = base + 64 * j + lane;
-        f[j] = k < n ? inst_flag[first + k] : (uint8_t)0;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) {
-        if (f[j]) {
-          const size_t slot = first + base + 64 * j + lane;
-          inst_flag[slot] = 0;  // consumed: the blobs are clean for another backward
-          const float4 a = grad_inst[slot * GRAD_F4 + 0];
-          const float4 b = grad_inst[slot * GRAD_F4 + 1];
-          const float4 c = grad_inst[slot * GRAD_F4 + 2];
-          v0 += a.x; v1 += a.y; v2 += a.z; v3 += a.w;
-          v4 += b.x; v5 += b.y; v6 += b.z; v7 += b.w;
-          v8 += (c.x + c.y) + (c.z + c.w);  // the four 16-lane-row sums of dLG the tile kernel leaves
-        }
-      }
+    if (threadIdx.x == 0) s_nlong = 0u;
+    __syncthreads();
+    const uint32_t qc = base + ((uint32_t)lane * NW + (uint32_t)w) * gridDim.x + blockIdx.x;
+    uint32_t cand = 0xFFFFFFFFu;
+    if (qc < count) cand = !from_descriptors ? g.tlist[qc] : qc < nA ? g.sdesc[qc].y : g.sdescB[qc - nA].y;
+    // (emitted, but no pixel took it: no record)
+    const bool has = cand < (uint32_t)P && (!from_descriptors || g.touched[cand] != 0);
+    // Every lane fetches what the gather of ITS candidate will need -- first slot, run length, the splat record's conic
+    // and opacity -- in one round trip for the whole batch; the wave then picks them up with v_readlane instead of
+    // starting each Gaussian with two dependent loads.
+    uint32_t my_first = 0u, my_n = 0u;
+    float4 my_ra = make_float4(0.f, 0.f, 0.f, 0.f), my_rb = my_ra;
+    if (has) {
+      my_first = g.slotinfo[cand].x;
+      my_n = g.gpack[cand].x;
+      my_ra = g.splats[(size_t)cand * SPLAT_F4 + 0];  // (x, y, conic.x, conic.y)
+      my_rb = g.splats[(size_t)cand * SPLAT_F4 + 1];  // (conic.z, opacity, r, g)
     }
-    // wave reduction: (v0,v4) (v1,v5) (v2,v6) (v3,v7) across half-waves, then rows, then inside rows
-    swap_add32_(v0, v4);
-    swap_add32_(v1, v5);
-    swap_add32_(v2, v6);
-    swap_add32_(v3, v7);
-    swap_add16_(v0, v2);  // rows hold v0, v2, v4, v6
-    swap_add16_(v1, v3);  // rows hold v1, v3, v5, v7
-    const float w0 = row_allsum_(v0), w1 = row_allsum_(v1);
-    v8 = row_allsum_(v8);
-    v8 += dpp_get_<0x142, 0xA>(v8);  // row_bcast:15
-    v8 += dpp_get_<0x143, 0xC>(v8);  // row_bcast:31 -> total in lane 63
-    // The records hold RAW pixel sums (colour r g b | S3 = sum dLG dx, S4 = sum dLG dy | S5 = sum dLG dx^2,
-    // S6 = sum dLG dx dy, S7 = sum dLG dy^2 | sum dLG), dLG = G dL/dalpha.  The factors every pixel and every instance
-    // of the Gaussian share are applied here, ONCE per Gaussian (backward.cu:561-562, 583-597):
-    //   dL/dmean2D = -(conic (S3, S4)) * opacity * (W/2, H/2),  dL/dconic = -1/2 opacity (S5, S6, S7),  dL/dopacity = sum dLG
-    const float S3 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w1), 16));
-    const float S4 = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(w0), 32));
-    const float4 ra = g.splats[(size_t)id * SPLAT_F4 + 0];  // (x, y, conic.x, conic.y)
-    const float4 rb = g.splats[(size_t)id * SPLAT_F4 + 1];  // (conic.z, opacity, r, g)
-    const float op = rb.y, mc = -0.5f * op;
-    if (lane == 0) { dL_dcolor[3 * id] = w0; dL_dcolor[3 * id + 1] = w1; }
-    if (lane == 16) { dL_dcolor[3 * id + 2] = w0; dL_dmean2D[3 * id] = -(ra.z * S3 + ra.w * S4) * (op * ddelx_dx); }
-    if (lane == 32) { dL_dmean2D[3 * id + 1] = -(rb.x * S4 + ra.w * S3) * (op * ddely_dy); dL_dconic[4 * id] = w1 * mc; }
-    if (lane == 48) { dL_dconic[4 * id + 1] = w0 * mc; dL_dconic[4 * id + 3] = w1 * mc; }
-    if (lane == 63) dL_dopacity[id] = v8;
-  }
+    const bool is_long = has && my_n > GATHER_SHARED_FROM;
+    if (is_long) s_long[atomicAdd(&s_nlong, 1u)] = cand;  // (list order is arbitrary: every entry is gathered independently)
+    for (uint64_t todo = __ballot(has && !is_long); todo != 0ull; todo &= todo - 1ull) {
+      const int src = __builtin_ctzll(todo);
+      const uint32_t id = (uint32_t)__builtin_amdgcn_readlane((int)cand, src);
+      const size_t first = (uint32_t)__builtin_amdgcn_readlane((int)my_first, src);
+      const uint32_t n = (uint32_t)__builtin_amdgcn_readlane((int)my_n, src);
+      RecordSums r;
+      for (uint32_t cb = 0; cb < n; cb += GATHER_CHUNK) gather_chunk(first, n, cb, lane, grad_inst, inst_flag, r);
+      gather_finish(r, id, lane, __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_ra.z), src)),
+                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_ra.w), src)),
+                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_rb.x), src)),
+                    __int_as_float(__builtin_amdgcn_readlane(__float_as_int(my_rb.y), src)), ddelx_dx, ddely_dy, dL_dmean2D,
+                    dL_dconic, dL_dopacity, dL_dcolor);
+    }
+    __syncthreads();
+    const uint32_t nlong = s_nlong;
+    for (uint32_t i = 0; i < nlong; i++) {
+      const uint32_t id = s_long[i];
+      const size_t first = g.slotinfo[id].x;
+      const uint32_t n = g.gpack[id].x;
+      RecordSums r;
+      for (uint32_t cb = (uint32_t)w * GATHER_CHUNK; cb < n; cb += NW * GATHER_CHUNK)
+        gather_chunk(first, n, cb, lane, grad_inst, inst_flag, r);
+      s_part[w][0][lane] = r.v0; s_part[w][1][lane] = r.v1; s_part[w][2][lane] = r.v2;
+      s_part[w][3][lane] = r.v3; s_part[w][4][lane] = r.v4; s_part[w][5][lane] = r.v5;
+      s_part[w][6][lane] = r.v6; s_part[w][7][lane] = r.v7; s_part[w][8][lane] = r.v8;
+      __syncthreads();
+      if (w == 0) {
+        RecordSums t;
+        float* tv[9] = {&t.v0, &t.v1, &t.v2, &t.v3, &t.v4, &t.v5, &t.v6, &t.v7, &t.v8};
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+          float acc = s_part[0][k][lane];
+#pragma unroll
+          for (int ww = 1; ww < NW; ww++) acc += s_part[ww][k][lane];
+          *tv[k] = acc;
+        }
+        const float4 ra = g.splats[(size_t)id * SPLAT_F4 + 0];
+        const float4 rb = g.splats[(size_t)id * SPLAT_F4 + 1];
+        gather_finish(t, id, lane, ra.z, ra.w, rb.x, rb.y, ddelx_dx, ddely_dy, dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor);
+      }
+      __syncthreads();
+    }
+    __syncthreads();  // (every wave has read this round's s_nlong before thread 0 clears it for the next)
   }
 }
 
