@@ -333,55 +333,6 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
       c = splats[(size_t)id * SPLAT_F4 + 2];
       hit = splat_hits_quad(a, b, c, qx0, qy0);
     }
-    // Visit loop, software-pipelined by hand: the LDS broadcast reads of the NEXT hit are issued before the
-    // current hit is blended (two register sets, no copies), so their latency hides behind ~30 VALU ops.
-    auto blend = [&](const float4 ra, const float4 rb, const float4 rc) {
-      const float dx = ra.x - pfx, dy = ra.y - pfy;
-      const float power = splat_power(ra.z, ra.w, rb.x, dx, dy);  // = log2(e) x the reference's power
-      const float alpha = fminf(0.99f, rb.y * __builtin_amdgcn_exp2f(power));
-      // forward.cu:367-383: skip on power > 0 and alpha < 1/255; a pixel whose T would fall below 1e-4 stops BEFORE taking
-      // the splat.  Three compares straight into lane masks, the rest is scalar mask arithmetic.
-      const uint64_t take = __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
-                            __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f)) & ~done_m;
-      const float test_T = T * (1.0f - alpha);
-      const uint64_t low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
-      done_m |= take & low;
-      const uint64_t ok = take & ~low;
-#if GSR_FWD_EXEC_MASK
-      // The pixels that take the splat update their sums, T and last contributor under the execution mask `ok`: eight
-      // plain instructions.  (With selects -- weight or 0, new or old T, new or old position -- it is nine, three of
-      // them v_cndmask_b32 at 1.6 times the issue cost of a multiply-add: tools/microbench/valu_probe.hip.)  The compiler cannot
-      // be told to use a scalar lane mask as a branch condition without deriving a per-lane flag from it first, hence
-      // the assembly; the wave's execution mask is restored before anything else runs.
-      uint64_t exec_save;
-      float wgt;
-      asm volatile(
-          "s_and_saveexec_b64 %[sv], %[ok]\n\t"
-          "v_mul_f32_e32 %[w], %[al], %[T]\n\t"
-          "v_fmac_f32_e32 %[C0], %[cr], %[w]\n\t"
-          "v_fmac_f32_e32 %[C1], %[cg], %[w]\n\t"
-          "v_fmac_f32_e32 %[C2], %[cb], %[w]\n\t"
-          "v_fmac_f32_e32 %[Dp], %[dz], %[w]\n\t"
-          "v_add_f32_e32 %[A], %[A], %[w]\n\t"
-          "v_mov_b32_e32 %[T], %[tT]\n\t"
-          "v_mov_b32_e32 %[last], %[pos]\n\t"
-          "s_mov_b64 exec, %[sv]"
-          : [sv] "=&s"(exec_save), [w] "=&v"(wgt), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [Dp] "+v"(Dp), [A] "+v"(A),
-            [T] "+v"(T), [last] "+v"(last)
-          : [ok] "s"(ok), [al] "v"(alpha), [cr] "v"(rb.z), [cg] "v"(rb.w), [cb] "v"(rc.x), [dz] "v"(rc.y), [tT] "v"(test_T),
-            [pos] "v"(rc.z)
-          : "scc");
-#else
-      const float wgt = sel_f0(ok, alpha * T);
-      C0 += rb.z * wgt;
-      C1 += rb.w * wgt;
-      C2 += rc.x * wgt;
-      Dp += rc.y * wgt;
-      A += wgt;
-      T = sel_f(ok, test_T, T);
-      last = sel_u(ok, __float_as_uint(rc.z), last);
-#endif
-    };
 #if GSR_FWD_ASM_VISIT
     // One visit = one block of assembly: 23 vector and 4 scalar instructions.  The skip / stop rules of forward.cu:367-383
     // narrow the execution mask step by step -- not-yet-stopped pixels (s_andn1_saveexec), power <= 0 and alpha >= 1/255
@@ -389,7 +340,7 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
     // pixels still active take the splat.  As C++ the same rules cost 13 scalar instructions per visit (lane masks
     // combined with s_and / s_or / s_andn2, loop flags through s_cselect and vcc branches): 43 M per frame at 2 M Gaussians /
     // 1080p on the ONE scalar unit the CU's waves share, which was as busy as the vector units (profiles/r03e_sq_probe.txt).
-    // Same arithmetic, same order of roundings as `blend` above: images and n_contrib are bit-identical.
+    // Same arithmetic, same order of roundings as the C++ visit (`blend`, below): images and n_contrib are bit-identical.
     auto visit = [&](const float4 ra, const float4 rb, const float4 rc) {
       float t0, t1, dx, dy;
       uint64_t sv;
@@ -458,6 +409,55 @@ __global__ __launch_bounds__(64 * FW) void k_blend_forward(const FrameParams fp,
       }
     }
 #else
+    // Visit loop, software-pipelined by hand: the LDS broadcast reads of the NEXT hit are issued before the
+    // current hit is blended (two register sets, no copies), so their latency hides behind ~30 VALU ops.
+    auto blend = [&](const float4 ra, const float4 rb, const float4 rc) {
+      const float dx = ra.x - pfx, dy = ra.y - pfy;
+      const float power = splat_power(ra.z, ra.w, rb.x, dx, dy);  // = log2(e) x the reference's power
+      const float alpha = fminf(0.99f, rb.y * __builtin_amdgcn_exp2f(power));
+      // forward.cu:367-383: skip on power > 0 and alpha < 1/255; a pixel whose T would fall below 1e-4 stops BEFORE taking
+      // the splat.  Three compares straight into lane masks, the rest is scalar mask arithmetic.
+      const uint64_t take = __builtin_amdgcn_ballot_w64(!(power > 0.0f)) &
+                            __builtin_amdgcn_ballot_w64(!(alpha < 1.0f / 255.0f)) & ~done_m;
+      const float test_T = T * (1.0f - alpha);
+      const uint64_t low = __builtin_amdgcn_ballot_w64(test_T < 0.0001f);
+      done_m |= take & low;
+      const uint64_t ok = take & ~low;
+#if GSR_FWD_EXEC_MASK
+      // The pixels that take the splat update their sums, T and last contributor under the execution mask `ok`: eight
+      // plain instructions.  (With selects -- weight or 0, new or old T, new or old position -- it is nine, three of
+      // them v_cndmask_b32 at 1.6 times the issue cost of a multiply-add: tools/microbench/valu_probe.hip.)  The compiler cannot
+      // be told to use a scalar lane mask as a branch condition without deriving a per-lane flag from it first, hence
+      // the assembly; the wave's execution mask is restored before anything else runs.
+      uint64_t exec_save;
+      float wgt;
+      asm volatile(
+          "s_and_saveexec_b64 %[sv], %[ok]\n\t"
+          "v_mul_f32_e32 %[w], %[al], %[T]\n\t"
+          "v_fmac_f32_e32 %[C0], %[cr], %[w]\n\t"
+          "v_fmac_f32_e32 %[C1], %[cg], %[w]\n\t"
+          "v_fmac_f32_e32 %[C2], %[cb], %[w]\n\t"
+          "v_fmac_f32_e32 %[Dp], %[dz], %[w]\n\t"
+          "v_add_f32_e32 %[A], %[A], %[w]\n\t"
+          "v_mov_b32_e32 %[T], %[tT]\n\t"
+          "v_mov_b32_e32 %[last], %[pos]\n\t"
+          "s_mov_b64 exec, %[sv]"
+          : [sv] "=&s"(exec_save), [w] "=&v"(wgt), [C0] "+v"(C0), [C1] "+v"(C1), [C2] "+v"(C2), [Dp] "+v"(Dp), [A] "+v"(A),
+            [T] "+v"(T), [last] "+v"(last)
+          : [ok] "s"(ok), [al] "v"(alpha), [cr] "v"(rb.z), [cg] "v"(rb.w), [cb] "v"(rc.x), [dz] "v"(rc.y), [tT] "v"(test_T),
+            [pos] "v"(rc.z)
+          : "scc");
+#else
+      const float wgt = sel_f0(ok, alpha * T);
+      C0 += rb.z * wgt;
+      C1 += rb.w * wgt;
+      C2 += rc.x * wgt;
+      Dp += rc.y * wgt;
+      A += wgt;
+      T = sel_f(ok, test_T, T);
+      last = sel_u(ok, __float_as_uint(rc.z), last);
+#endif
+    };
     if (nh) {
       float4 a0 = sA[0], b0 = sB[0], c0 = sC[0], a1, b1, c1;
       for (int r = 0;; r += 2) {
