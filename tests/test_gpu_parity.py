@@ -670,6 +670,22 @@ def test_screen_filling_splats_and_long_lists(mode, gpu_device):
     assert (r[:, 1] - r[:, 0]).max() > 512 and fr.tiles_touched.max() >= 100
 
 
+def test_screen_filling_runs_shared_by_the_gather(gpu_device):
+    """Gaussians that cover the whole image at 1024 x 768 (3072 tiles): their slot runs are longer than the 2048 slots
+    from which k_gather_records shares a run among the four waves of a workgroup (a camera that turns towards a near
+    Gaussian sees such splats).  Against the oracle, and one chain (gather over the touched list) against near/far
+    (gather over the chains' descriptors) bit for bit."""
+    sc = S.make_scene(3000, 1024, 768, 31, sh_degree=0)
+    sc["means3D"][:12, 2] = np.linspace(1.0, 1.3, 12, dtype=np.float32)
+    sc["means3D"][:12, :2] *= 0.02
+    sc["scales"][:12] = 0.3       # (larger ones are culled: the reference drops splats beyond a radius limit)
+    sc["opacities"][:12] = 0.04   # (thin: every pixel keeps taking splats behind them)
+    fr, _ = _full_check(sc, gpu_device, seed=31, mode="culled")
+    assert int((fr.tiles_touched > 2048).sum()) >= 12
+    st = _check_near_far_against_one_chain(sc, gpu_device, near_entries=6)
+    assert st["far"] > 0
+
+
 @pytest.mark.parametrize("mode", MODES)
 def test_depth_ties_keep_id_order(mode, gpu_device):
     """Thousands of Gaussians share each of a few depths: inside a tile the reference's 64-bit keys then tie and its
