@@ -678,7 +678,7 @@ def test_screen_filling_runs_shared_by_the_gather(gpu_device):
     sc = S.make_scene(3000, 1024, 768, 31, sh_degree=0)
     sc["means3D"][:12, 2] = np.linspace(1.0, 1.3, 12, dtype=np.float32)
     sc["means3D"][:12, :2] *= 0.02
-    sc["scales"][:12] = 0.3       # (larger ones are culled: the reference drops splats beyond a radius limit)
+    sc["scales"][:12] = 0.3       # (the largest the reference draws: scale x modifier > 0.3 is culled, forward.cu:227-229)
     sc["opacities"][:12] = 0.04   # (thin: every pixel keeps taking splats behind them)
     fr, _ = _full_check(sc, gpu_device, seed=31, mode="culled")
     assert int((fr.tiles_touched > 2048).sum()) >= 12
