@@ -147,6 +147,8 @@ def parse_args():
     ap.add_argument("--opacity-scale", type=float, default=1.0,
                     help="multiplies the scene's opacities (0.1: a scene whose tiles never saturate inside the near budget "
                          "-- the one-chain floor of the forward)")
+    ap.add_argument("--near-entries", type=int, default=0,
+                    help="diagnostic: fix the near budget at this many list entries per tile (the adaptive rule is off)")
     ap.add_argument("--per-step", action="store_true",
                     help="after the timed region: an extra pass of the same steps, synchronised one by one, whose ms and "
                          "speculation counters per step go into the line under 'per_step' (diagnostic, never `value`)")
@@ -209,6 +211,8 @@ def main():
                   file=sys.stderr)
     n_gpus = world
     G.set_reference_rects(args.reference_rects)
+    if args.near_entries > 0:  # (main thread only: a measurement knob for single-thread runs)
+        G.set_near_far_hints(near_entries_per_tile=args.near_entries)
 
     P, W, H, seed = S.CONFIGS[args.workload]
     D = args.sh_degree
@@ -506,7 +510,7 @@ def main():
     # on this workload with these flags (their "_meta"), otherwise the fields stay null.
     this_meta = dict(workload=args.workload, sh_degree=D, loss=args.loss, forward_only=bool(args.forward_only),
                      reference_rects=bool(args.reference_rects), n_gpus=n_gpus)
-    plain_run = K == 1 and not rotate and not args.grow_every and args.opacity_scale == 1.0
+    plain_run = K == 1 and not rotate and not args.grow_every and args.opacity_scale == 1.0 and not args.near_entries
 
     def committed(fname):
         try:
@@ -576,7 +580,7 @@ def main():
                    "camera": "the C4 yaw cameras in turn, a different one every forward" if rotate else "one fixed view",
                    "grow": (dict(every_steps=args.grow_every, points=args.grow_points, added=main_run["grown"],
                                  P_at_end=P) if args.grow_every else None),
-                   "opacity_scale": args.opacity_scale,
+                   "opacity_scale": args.opacity_scale, "near_entries": args.near_entries,
                    "parallelism": "view-parallel x%d" % n_gpus,
                    "sync_mode": args.sync_mode if n_gpus > 1 else None,
                    "adam_in_step": not (args.no_adam or args.forward_only),
