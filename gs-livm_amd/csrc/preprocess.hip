@@ -185,6 +185,28 @@ __device__ __forceinline__ void lds_to_rows(float* __restrict__ dst, const float
   }
 }
 
+// The rows of the listed Gaussians only (block-local row numbers in `list`, `nlist` of them): the backward needs the SH
+// coefficients of the Gaussians that carry a gradient record -- a few per cent of a dense scene -- and writes zeros for
+// the rest.  Row-major chunks of 16 bytes when the rows allow it, single floats otherwise.
+__device__ __forceinline__ void listed_rows_to_lds(float* lds, const float* __restrict__ src, const uint32_t* list,
+                                                   const int nlist, const int C) {
+  const int S = sh_row_stride(C);
+  if ((C & 3) == 0 && (reinterpret_cast<uintptr_t>(src) & 15u) == 0) {  // block-uniform
+    const int C4 = C >> 2;
+    for (int k = threadIdx.x; k < nlist * C4; k += PRE_BLOCK) {
+      const int r = (int)list[k / C4], c4 = k % C4;
+      const float4 v = reinterpret_cast<const float4*>(src + (size_t)r * C)[c4];
+      float* d = lds + r * S + 4 * c4;
+      d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+  } else {
+    for (int k = threadIdx.x; k < nlist * C; k += PRE_BLOCK) {
+      const int r = (int)list[k / C], c = k % C;
+      lds[r * S + c] = src[(size_t)r * C + c];
+    }
+  }
+}
+
 // bytes of dynamic LDS the staged variants need; 0 = do not stage (M == 1, or rows too long for 64 KB)
 static inline size_t sh_stage_bytes(int M) {
   if (M <= 1) return 0;
@@ -1497,15 +1519,38 @@ __device__ __forceinline__ void gaussian_backward_one(
     float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
     float* __restrict__ dL_drot) {
-  // Every input of the Gaussian is requested up front and unconditionally -- one memory round trip instead of one
-  // per stage (radii / touched -> record sums -> mean, covariance -> clamp bits -> scale, rotation); what a culled
-  // or untouched Gaussian reads that way is never used (selects, not arithmetic: stale bits cannot leak).
+  // Two round trips: the Gaussian's radius and "touched" flag first -- a Gaussian without a gradient record (culled, or
+  // visible but taken by no pixel: 97 % of the scene in a dense near/far frame) gets its zeros written and reads nothing
+  // else -- then, for the others, every remaining input at once (record sums, mean, covariance inputs, clamp bits)
+  // rather than one round trip per stage.  (Round 2 requested everything up front for every Gaussian: one round trip,
+  // but 94 bytes read per Gaussian that only the touched ones need.)
   const int rad_in = radii[idx];
   const uint8_t touched_in = g.touched[idx];
-  const float i_col0 = dL_dcolor[3 * idx], i_col1 = dL_dcolor[3 * idx + 1], i_col2 = dL_dcolor[3 * idx + 2];
-  const float i_mx = dL_dmean2D[3 * idx], i_my = dL_dmean2D[3 * idx + 1];
-  const float i_ca = dL_dconic[4 * idx], i_cb = dL_dconic[4 * idx + 1], i_cc = dL_dconic[4 * idx + 3];
-  const float i_op = dL_dopacity[idx];
+  const bool vis = rad_in > 0;
+  const int M = fp.M;
+  float* gs = row ? row : dL_dsh + (size_t)idx * fp.M * 3;
+  if (idx == 0) g.total[2] = 0u;  // the touched list has been consumed (k_gather_records ran before this kernel)
+  const bool was_touched = touched_in != 0;
+  if (was_touched) g.touched[idx] = 0;  // leave the blobs clean for another backward over them
+  const bool rec = vis && was_touched;  // sums left by k_gather_records; everything else has no record at all
+  if (!rec) {  // every gradient of this Gaussian is zero (with all-zero record sums the chain below yields zeros)
+    dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
+    dL_dconic[4 * idx] = 0.f; dL_dconic[4 * idx + 1] = 0.f; dL_dconic[4 * idx + 2] = 0.f; dL_dconic[4 * idx + 3] = 0.f;
+    dL_dopacity[idx] = 0.f;
+    dL_dcolor[3 * idx] = 0.f; dL_dcolor[3 * idx + 1] = 0.f; dL_dcolor[3 * idx + 2] = 0.f;
+    dL_dmean3D[3 * idx] = 0.f; dL_dmean3D[3 * idx + 1] = 0.f; dL_dmean3D[3 * idx + 2] = 0.f;
+    if (dL_dcov3D) {  // (null: the 3-D covariance is not an input of the caller's graph, nobody reads its gradient)
+#pragma unroll
+      for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = 0.f;
+    }
+    for (int k = 0; k < 3 * M; k++) gs[k] = 0.f;
+    dL_dscale[3 * idx] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f;
+    dL_drot[4 * idx] = 0.f; dL_drot[4 * idx + 1] = 0.f; dL_drot[4 * idx + 2] = 0.f; dL_drot[4 * idx + 3] = 0.f;
+    return;
+  }
+  const float gcol0 = dL_dcolor[3 * idx], gcol1 = dL_dcolor[3 * idx + 1], gcol2 = dL_dcolor[3 * idx + 2];
+  const float gmx = dL_dmean2D[3 * idx], gmy = dL_dmean2D[3 * idx + 1];
+  const float gca = dL_dconic[4 * idx], gcb = dL_dconic[4 * idx + 1], gcc = dL_dconic[4 * idx + 3];
   const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
   const uint8_t clamped_in = g.clamped[idx];
   float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1524,33 +1569,11 @@ __device__ __forceinline__ void gaussian_backward_one(
   } else {
     cov3d_from_scale_rot(fp.scale_modifier * sc_in[0], fp.scale_modifier * sc_in[1], fp.scale_modifier * sc_in[2], q_in, c6);
   }
-  const bool vis = rad_in > 0;
   const float* sh = row ? row : shs + (size_t)idx * fp.M * 3;
-  float* gs = row ? row : dL_dsh + (size_t)idx * fp.M * 3;
-  // ---- gather-sum of the instance records ----
-  if (idx == 0) g.total[2] = 0u;  // the touched list has been consumed (k_gather_records ran before this kernel)
-  const bool was_touched = touched_in != 0;
-  if (was_touched) g.touched[idx] = 0;  // leave the blobs clean for another backward over them
-  const bool rec = vis && was_touched;  // sums left by k_gather_records; everything else has no record at all
-  const float gcol0 = rec ? i_col0 : 0.f, gcol1 = rec ? i_col1 : 0.f, gcol2 = rec ? i_col2 : 0.f;
-  const float gmx = rec ? i_mx : 0.f, gmy = rec ? i_my : 0.f;
-  const float gca = rec ? i_ca : 0.f, gcb = rec ? i_cb : 0.f, gcc = rec ? i_cc : 0.f, gop = rec ? i_op : 0.f;
-  dL_dmean2D[3 * idx] = gmx; dL_dmean2D[3 * idx + 1] = gmy; dL_dmean2D[3 * idx + 2] = 0.f;
-  dL_dconic[4 * idx] = gca; dL_dconic[4 * idx + 1] = gcb; dL_dconic[4 * idx + 2] = 0.f; dL_dconic[4 * idx + 3] = gcc;
-  dL_dopacity[idx] = gop;
-  dL_dcolor[3 * idx] = gcol0; dL_dcolor[3 * idx + 1] = gcol1; dL_dcolor[3 * idx + 2] = gcol2;
-  const int M = fp.M;
-  if (!vis) {
-    dL_dmean3D[3 * idx] = 0.f; dL_dmean3D[3 * idx + 1] = 0.f; dL_dmean3D[3 * idx + 2] = 0.f;
-    if (dL_dcov3D) {  // (null: the 3-D covariance is not an input of the caller's graph, nobody reads its gradient)
-#pragma unroll
-      for (int k = 0; k < 6; k++) dL_dcov3D[6 * (size_t)idx + k] = 0.f;
-    }
-    for (int k = 0; k < 3 * M; k++) gs[k] = 0.f;
-    dL_dscale[3 * idx] = 0.f; dL_dscale[3 * idx + 1] = 0.f; dL_dscale[3 * idx + 2] = 0.f;
-    dL_drot[4 * idx] = 0.f; dL_drot[4 * idx + 1] = 0.f; dL_drot[4 * idx + 2] = 0.f; dL_drot[4 * idx + 3] = 0.f;
-    return;
-  }
+  // (the record sums stay where k_gather_records left them: they are this kernel's dL_dmean2D / dL_dconic / dL_dopacity /
+  // dL_dcolor outputs as well; the unused third / fourth components are zeroed)
+  dL_dmean2D[3 * idx + 2] = 0.f;
+  dL_dconic[4 * idx + 2] = 0.f;
   // ---- B2: conic -> cov2D -> cov3D and mean (backward.cu:140-275) ----
   const Ewa e = ewa_project(mx, my, mz, fp, c6, V);
   const float limx = 1.3f * fp.tan_fovx, limy = 1.3f * fp.tan_fovy;
@@ -1739,11 +1762,18 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
     float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
     float* __restrict__ dL_drot) {
-  extern __shared__ float sh_rows[];  // STAGED: SH rows in, dL_dsh rows out (rows_to_lds / lds_to_rows)
+  extern __shared__ float sh_rows[];  // STAGED: SH rows in, dL_dsh rows out (listed_rows_to_lds / lds_to_rows)
+  __shared__ uint32_t s_rec[PRE_BLOCK];  // STAGED: block-local rows of the Gaussians with a gradient record
+  __shared__ uint32_t s_nrec;
   const int row0 = blockIdx.x * PRE_BLOCK, idx = row0 + threadIdx.x;
   const int C = fp.M * 3, nrows = min(PRE_BLOCK, fp.P - row0);
   if (STAGED) {
-    rows_to_lds(sh_rows, shs + (size_t)row0 * C, nrows, C);
+    // only the rows gaussian_backward_one will read (same test as there; the flags are cleared by that function, later)
+    if (threadIdx.x == 0) s_nrec = 0u;
+    __syncthreads();
+    if (idx < fp.P && radii[idx] > 0 && g.touched[idx] != 0) s_rec[atomicAdd(&s_nrec, 1u)] = threadIdx.x;
+    __syncthreads();
+    listed_rows_to_lds(sh_rows, shs + (size_t)row0 * C, s_rec, (int)s_nrec, C);
     __syncthreads();
   }
   if (idx < fp.P)
