@@ -706,6 +706,31 @@ static void lazy_push(ThreadCtx& c, uint32_t ticket, uint32_t near, uint32_t tot
   c.pending_n++;
 }
 
+// Are several host threads rendering at the moment?  (Two hand-overs of "the thread that entered gsr_forward last" within
+// the last 100 ms: a loop that renders its views from T > 1 threads switches several times per iteration, a process
+// whose only rendering thread changes once does not count.)  Such a process gets no asynchronous frames: with other
+// threads' work on the GPU the host-decided far chain's wait costs nothing (three views from three threads, 2 M Gaussians /
+// 1080p: 0.698 ms per view against 0.744 with one thread's frames asynchronous), and it keeps the second stream and the
+// stream-side waits -- a Beta interface -- out of a process whose five or more streams already share the device's few
+// hardware queues.  (That combination is where the one GPU memory fault of round 3 appeared, DESIGN.md section 4: three
+// rendering threads, reproducible, gone with GSR_ASYNC_FAR=0, with serialised kernels, and with a slower backward.)
+static std::mutex g_switch_mu;
+static const void* g_last_forward_thread = nullptr;
+static std::chrono::steady_clock::time_point g_switch_time[2];  // the last two hand-overs, most recent first
+static bool several_threads_render(const void* me) {
+  const std::chrono::steady_clock::time_point now = std::chrono::steady_clock::now();
+  std::lock_guard<std::mutex> lk(g_switch_mu);
+  if (g_last_forward_thread != me) {
+    if (g_last_forward_thread != nullptr) {
+      g_switch_time[1] = g_switch_time[0];
+      g_switch_time[0] = now;
+    }
+    g_last_forward_thread = me;
+  }
+  return g_switch_time[1] != std::chrono::steady_clock::time_point() &&
+         now - g_switch_time[1] < std::chrono::milliseconds(100);
+}
+
 // One binning chain: scan -> emit -> tile sort -> ranges, followed by the blend.  A whole frame is one chain over the
 // blob (phase 0).  A near/far frame (gsr_forward) runs two chains over ONE blob carved for capA + capB instances:
 // phase 1 bins the near Gaussians into slots / list positions [0, capA), phase 2 the far Gaussians that still matter
@@ -864,6 +889,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   //     waits for the host.  If R exceeds the capacity the kernels have clamped to it (in-bounds garbage); the
   //     host then allocates an exact blob and enqueues the binning chain again -- the only cost of a misprediction.
   ThreadCtx& c = g_ctx;
+  const bool multi_thread = several_threads_render(&c);
   lazy_resolve(c);  // (what the thread's earlier asynchronous frames left open, as far as the mailbox has it by now)
   c.w_live = 3;
   c.w_far = 1;
@@ -1032,7 +1058,7 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
       //   * otherwise decided by the host: the near blend publishes the count of unfinished quads to the mailbox and the
       //     far chain is enqueued only if there are any (one host round trip instead of eleven idle launches).
       // The near blend parks the unfinished pixels' state in the same way in every variant: same result.
-      const bool async_far = speculate_far && async_far_ready(c);
+      const bool async_far = speculate_far && !multi_thread && async_far_ready(c);
       const bool skip_far = speculate_far && !async_far;
       // (Measured and not kept: frames that enqueue their far chain outright sizing the far segment like the asynchronous
       // ones and returning without waiting for the far count.  Eight views per iteration from one thread: 0.985 -> 0.994 ms

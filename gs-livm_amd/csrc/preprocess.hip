@@ -1518,7 +1518,7 @@ __device__ __forceinline__ void gaussian_backward_one(
     const int colors_are_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
     float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
-    float* __restrict__ dL_drot) {
+    float* __restrict__ dL_drot, const bool skip_recordless) {
   // Two round trips: the Gaussian's radius and "touched" flag first -- a Gaussian without a gradient record (culled, or
   // visible but taken by no pixel: 97 % of the scene in a dense near/far frame) gets its zeros written and reads nothing
   // else -- then, for the others, every remaining input at once (record sums, mean, covariance inputs, clamp bits)
@@ -1533,7 +1533,7 @@ __device__ __forceinline__ void gaussian_backward_one(
   const bool was_touched = touched_in != 0;
   if (was_touched) g.touched[idx] = 0;  // leave the blobs clean for another backward over them
   const bool rec = vis && was_touched;  // sums left by k_gather_records; everything else has no record at all
-  if (!rec) {  // every gradient of this Gaussian is zero (with all-zero record sums the chain below yields zeros)
+  if (!rec && (skip_recordless || !vis)) {  // every gradient of this Gaussian is zero (with all-zero record sums the chain below yields zeros)
     dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f; dL_dmean2D[3 * idx + 2] = 0.f;
     dL_dconic[4 * idx] = 0.f; dL_dconic[4 * idx + 1] = 0.f; dL_dconic[4 * idx + 2] = 0.f; dL_dconic[4 * idx + 3] = 0.f;
     dL_dopacity[idx] = 0.f;
@@ -1548,9 +1548,16 @@ __device__ __forceinline__ void gaussian_backward_one(
     dL_drot[4 * idx] = 0.f; dL_drot[4 * idx + 1] = 0.f; dL_drot[4 * idx + 2] = 0.f; dL_drot[4 * idx + 3] = 0.f;
     return;
   }
-  const float gcol0 = dL_dcolor[3 * idx], gcol1 = dL_dcolor[3 * idx + 1], gcol2 = dL_dcolor[3 * idx + 2];
-  const float gmx = dL_dmean2D[3 * idx], gmy = dL_dmean2D[3 * idx + 1];
-  const float gca = dL_dconic[4 * idx], gcb = dL_dconic[4 * idx + 1], gcc = dL_dconic[4 * idx + 3];
+  // (skip_recordless off -- GSR_GBWD_ALL=1, diagnostics --: a visible Gaussian without a record walks the chain with zero sums)
+  const float gcol0 = rec ? dL_dcolor[3 * idx] : 0.f, gcol1 = rec ? dL_dcolor[3 * idx + 1] : 0.f, gcol2 = rec ? dL_dcolor[3 * idx + 2] : 0.f;
+  const float gmx = rec ? dL_dmean2D[3 * idx] : 0.f, gmy = rec ? dL_dmean2D[3 * idx + 1] : 0.f;
+  const float gca = rec ? dL_dconic[4 * idx] : 0.f, gcb = rec ? dL_dconic[4 * idx + 1] : 0.f, gcc = rec ? dL_dconic[4 * idx + 3] : 0.f;
+  if (!rec) {
+    dL_dmean2D[3 * idx] = 0.f; dL_dmean2D[3 * idx + 1] = 0.f;
+    dL_dconic[4 * idx] = 0.f; dL_dconic[4 * idx + 1] = 0.f; dL_dconic[4 * idx + 3] = 0.f;
+    dL_dopacity[idx] = 0.f;
+    dL_dcolor[3 * idx] = 0.f; dL_dcolor[3 * idx + 1] = 0.f; dL_dcolor[3 * idx + 2] = 0.f;
+  }
   const float mx = means3D[3 * idx], my = means3D[3 * idx + 1], mz = means3D[3 * idx + 2];
   const uint8_t clamped_in = g.clamped[idx];
   float4 q_in = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1761,7 +1768,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
     const int colors_are_precomp, float* dL_dmean2D, float* dL_dconic, float* dL_dopacity, float* dL_dcolor,
     float* __restrict__ dL_dmean3D,
     float* __restrict__ dL_dcov3D, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
-    float* __restrict__ dL_drot) {
+    float* __restrict__ dL_drot, const bool skip_recordless) {
   extern __shared__ float sh_rows[];  // STAGED: SH rows in, dL_dsh rows out (listed_rows_to_lds / lds_to_rows)
   __shared__ uint32_t s_rec[PRE_BLOCK];  // STAGED: block-local rows of the Gaussians with a gradient record
   __shared__ uint32_t s_nrec;
@@ -1771,7 +1778,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
     // only the rows gaussian_backward_one will read (same test as there; the flags are cleared by that function, later)
     if (threadIdx.x == 0) s_nrec = 0u;
     __syncthreads();
-    if (idx < fp.P && radii[idx] > 0 && g.touched[idx] != 0) s_rec[atomicAdd(&s_nrec, 1u)] = threadIdx.x;
+    if (idx < fp.P && radii[idx] > 0 && (g.touched[idx] != 0 || !skip_recordless)) s_rec[atomicAdd(&s_nrec, 1u)] = threadIdx.x;
     __syncthreads();
     listed_rows_to_lds(sh_rows, shs + (size_t)row0 * C, s_rec, (int)s_nrec, C);
     __syncthreads();
@@ -1779,7 +1786,7 @@ __global__ __launch_bounds__(PRE_BLOCK) void k_gaussian_backward(
   if (idx < fp.P)
     gaussian_backward_one(idx, STAGED ? sh_rows + threadIdx.x * sh_row_stride(C) : nullptr, fp, g, radii, means3D, scales,
                           rotations, shs, cov3D_precomp, V, Pm, campos, colors_are_precomp, dL_dmean2D, dL_dconic,
-                          dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+                          dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot, skip_recordless);
   if (STAGED) {
     __syncthreads();
     lds_to_rows(dL_dsh + (size_t)row0 * C, sh_rows, nrows, C);
@@ -1963,14 +1970,17 @@ hipError_t launch_gaussian_backward(const FrameParams& fp, GeomState g, BinningS
   const int nb = (fp.P + PRE_BLOCK - 1) / PRE_BLOCK;
   ProfScope ps_k_gaussian_bwd(K_GAUSSIAN_BWD, s);
   const size_t stage = (shs && !colors_precomp) ? sh_stage_bytes(fp.M) : 0;  // M > 1: SH / dL_dsh rows go through LDS
+  static const bool skip_recordless = getenv("GSR_GBWD_ALL") == nullptr;  // (GSR_GBWD_ALL=1: diagnostics)
   if (stage)
     hipLaunchKernelGGL(k_gaussian_backward<true>, dim3(nb), dim3(PRE_BLOCK), stage, s, fp, g, radii,
                        means3D, scales, rotations, shs, cov3D_precomp, view, proj, campos, 0,
-                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                       skip_recordless);
   else
     hipLaunchKernelGGL(k_gaussian_backward<false>, dim3(nb), dim3(PRE_BLOCK), 0, s, fp, g, radii,
                        means3D, scales, rotations, shs, cov3D_precomp, view, proj, campos, colors_precomp ? 1 : 0,
-                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot);
+                       dL_dmean2D, dL_dconic, dL_dopacity, dL_dcolor, dL_dmean3D, dL_dcov3D, dL_dsh, dL_dscale, dL_drot,
+                       skip_recordless);
   return hipGetLastError();
 }
 
