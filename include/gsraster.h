@@ -116,7 +116,9 @@ unsigned long long gsr_near_far_forwards(void);
 /* Far-chain speculation.  When a thread's last two split forwards left no quad unfinished after the near
  * chain (a dense scene: the far chain's launches found nothing to do), its next split forward is
  *   - asynchronous, where the device supports stream-side waits (hipStreamWaitValue32; GSR_ASYNC_FAR=0
- *     switches this off): the far chain is enqueued on a stream of the library's own behind a wait for
+ *     switches this off) and while ONE host thread of the process is rendering (one thread at a time owns the
+ *     mechanism, and a process whose rendering hands over between threads twice within 100 ms takes the
+ *     host-decided variant below): the far chain is enqueued on a stream of the library's own behind a wait for
  *     the near blend's decision, each of its kernels gated on "needed", and the caller's stream waits
  *     for the frame's go word -- stored by the near blend itself when nothing is left to do, by the far
  *     chain's last kernel otherwise.  gsr_forward returns without waiting for the decision; the far
