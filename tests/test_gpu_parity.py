@@ -1253,10 +1253,14 @@ def test_views_rendered_from_several_threads_one_backward(gpu_device):
 
     img1, g1 = run(None)
     vt = MV.ViewThreads(3, dev)
+    async_before = G.speculation_stats()["async_far_frames"]
     try:
         img3, g3 = run(vt)
     finally:
         vt.close()
+    # while several host threads render, no frame takes the asynchronous far chain (second stream, stream-side waits):
+    # the host-decided variant costs nothing beside the other threads' work (include/gsraster.h)
+    assert G.speculation_stats()["async_far_frames"] == async_before
     for a, b in zip(img1, img3):
         assert torch.equal(a, b)
     for k in g1:
