@@ -889,7 +889,9 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
   //     waits for the host.  If R exceeds the capacity the kernels have clamped to it (in-bounds garbage); the
   //     host then allocates an exact blob and enqueues the binning chain again -- the only cost of a misprediction.
   ThreadCtx& c = g_ctx;
-  const bool multi_thread = several_threads_render(&c);
+  // (GSR_ASYNC_FAR_MT=1, diagnostics: asynchronous frames although several threads render -- the combination that faulted)
+  static const bool env_async_mt = getenv("GSR_ASYNC_FAR_MT") != nullptr;
+  const bool multi_thread = several_threads_render(&c) && !env_async_mt;
   lazy_resolve(c);  // (what the thread's earlier asynchronous frames left open, as far as the mailbox has it by now)
   c.w_live = 3;
   c.w_far = 1;
