@@ -1043,7 +1043,10 @@ int gsr_forward(gsr_alloc_fn geometry_alloc, void* geometry_ctx, gsr_alloc_fn bi
         c.far_hint_override = -1;
       } else if (h.have_far) {
         for (int k = 0; k < 4; k++) capB = h.recent_far[k] > capB ? h.recent_far[k] : capB;
-        capB = (uint32_t)std::min<unsigned long long>(0x7fffffffull - capA, (unsigned long long)capB * 5 / 4 + 65536);
+        // (half again as much as the view's recent far chains held: an overflow bins the whole frame a second time, ~1 ms
+        // at 2 M Gaussians, the margin costs 53 bytes per instance -- a camera that comes round every eighth iteration of a
+        // scene that is being optimised outgrew a quarter, twice in 72 frames)
+        capB = (uint32_t)std::min<unsigned long long>(0x7fffffffull - capA, (unsigned long long)capB * 3 / 2 + 131072);
         capB = std::min(round_capacity(capB), 0x7fffffffu - capA);
       } else {
         capB = hint > budget ? hint - budget : 0u;  // no history: room for every instance behind the budget
